@@ -1,0 +1,108 @@
+"""Pin the CPU oracle to the reference: bit-exact against arrays produced by the
+reference-emitted gold statement (oracle/make_golden.py) and against the
+known-answer values recorded in SURVEY.md section 8(c)."""
+import numpy as np
+import pytest
+
+import oracle
+from helpers import golden_cases, load_golden, stc_from_meta
+
+
+@pytest.mark.parametrize("case", golden_cases())
+def test_oracle_bit_exact_vs_reference_gold(case, tmp_path):
+    meta, a0, a_ref, b_ref = load_golden(case)
+    spec = oracle.Spec(stc_from_meta(tmp_path, meta), meta["ndim"], meta["step"])
+    assert spec.halo == meta["macros"]["Halo"]
+    assert spec.iterations == meta["macros"]["Iterations"]
+    # gold terms: same offsets in the same order, same printed coefficients
+    pts = spec.points
+    assert len(pts) == len(meta["terms"])
+    for (off, c), t in zip(pts, meta["terms"]):
+        assert list(off[3 - meta["ndim"]:]) == t["off"]
+        assert c == float(t["coef"])
+    # input stream == common.hpp rand() fill
+    A = oracle.fill_random(a0.shape, np.float64)
+    assert np.array_equal(A, a0)
+    B = np.zeros_like(A)
+    n = oracle.run(spec, A, B, contract=0)
+    assert n == meta["launches"] == spec.launches
+    assert np.array_equal(A, a_ref), "result buffer differs from reference gold"
+    assert np.array_equal(B, b_ref), "scratch buffer differs from reference gold"
+
+
+# values captured by the surveyor from the reference-emitted gold
+# (fp64, g++ -O0, glibc rand() seed 1), flat row-major indices.
+KNOWN = {
+    "tiny3d_s1": dict(idx=589, val=2.4920680248106066, sum_a=1401.2182949042365, sum_b=828.22812807166076),
+    "tiny3d_s2": dict(idx=589, val=2.4920680248106062, sum_a=906.5531129951529, sum_b=274.10139048942506),
+    "tiny2d_s1": dict(idx=71, val=0.66945895966050128, sum_a=89.047173596230323, sum_b=66.172632255245603),
+    "tiny2d_s2": dict(idx=71, val=0.66945895966050117, sum_a=83.186017546907522, sum_b=41.368072661662524),
+    "tiny25_s1": dict(idx=161, val=17.769162208746852, sum_a=2589.1001999063042, sum_b=1156.785215912282),
+    "tiny25_s2": dict(idx=161, val=17.769162208746845, sum_a=1435.9490754437454, sum_b=302.17625767997231),
+}
+
+
+@pytest.mark.parametrize("case", sorted(KNOWN))
+def test_oracle_vs_survey_known_answers(case, tmp_path):
+    meta, a0, _, _ = load_golden(case)
+    spec = oracle.Spec(stc_from_meta(tmp_path, meta), meta["ndim"], meta["step"])
+    A = oracle.fill_random(a0.shape, np.float64)
+    assert A.flat[0] == 0.84018771754595234
+    B = np.zeros_like(A)
+    oracle.run(spec, A, B, contract=0)
+    k = KNOWN[case]
+    assert A.flat[k["idx"]] == k["val"]
+    # the surveyor summed sequentially; allow last-digit summation-order noise
+    assert sum(A.flat) == pytest.approx(k["sum_a"], rel=1e-14)
+    assert sum(B.flat) == pytest.approx(k["sum_b"], rel=1e-14)
+
+
+def test_tiny2d_s1_second_pin(tmp_path):
+    meta, a0, _, _ = load_golden("tiny2d_s1")
+    spec = oracle.Spec(stc_from_meta(tmp_path, meta), 2, 1)
+    A = oracle.fill_random(a0.shape, np.float64)
+    B = np.zeros_like(A)
+    oracle.run(spec, A, B, contract=0)
+    assert A.flat[72] == 0.7234308752012728
+
+
+def test_fused_coefficient_multisets(tmp_path):
+    """SURVEY 8(c) 'Other pins': 3d7pt s=3 multiset and 2d25pt_box s=2 centre."""
+    from collections import Counter
+    meta, *_ = load_golden("tiny3d_s3")
+    spec = oracle.Spec(stc_from_meta(tmp_path, meta), 3, 3)
+    cnt = Counter(c for _, c in spec.points)
+    assert cnt == Counter({0.008: 6, 0.024: 24, 0.036: 6, 0.048: 8, 0.072: 12, 0.174: 6, 0.243: 1})
+    meta, *_ = load_golden("tiny25_s2")
+    spec = oracle.Spec(stc_from_meta(tmp_path, meta), 2, 2)
+    assert dict(spec.points)[(0, 0, 0)] == 0.3516
+
+
+def test_contract_modes_agree_to_rounding(tmp_path):
+    """fma-contracted order (what the HIP kernels compute) vs uncontracted: ~1 ulp/op."""
+    meta, a0, a_ref, _ = load_golden("tiny3d_s1")
+    spec = oracle.Spec(stc_from_meta(tmp_path, meta), 3, 1)
+    A = a0.copy(); B = np.zeros_like(A)
+    oracle.run(spec, A, B, contract=1)
+    m = oracle.check(spec, A, a_ref)
+    assert m["max_rel"] < 1e-14
+    A32 = a0.astype(np.float32); B32 = np.zeros_like(A32)
+    oracle.run(spec, A32, B32, contract=1)
+    m = oracle.check(spec, A32.astype(np.float64), a_ref)
+    assert m["max_rel"] < 1e-6
+
+
+def test_check_error_metric_matches_definition(tmp_path):
+    meta, a0, a_ref, _ = load_golden("tiny2d_s1")
+    spec = oracle.Spec(stc_from_meta(tmp_path, meta), 2, 1)
+    out = a_ref.copy()
+    out[5, 6] += 1e-3
+    out[0, 0] += 5.0   # ring: must be ignored (common.hpp:74-75 loops over the interior only)
+    m = oracle.check(spec, out, a_ref)
+    h = spec.halo
+    n_int = (a_ref.shape[0] - 2 * h) * (a_ref.shape[1] - 2 * h)
+    assert m["max_abs"] == pytest.approx(1e-3, rel=1e-9)
+    assert m["max_idx"] == 5 * a_ref.shape[1] + 6
+    assert m["rms"] == pytest.approx(np.sqrt(1e-6 / n_int), rel=1e-9)
+    m0 = oracle.check(spec, a_ref, a_ref)
+    assert m0["max_abs"] == 1e-13 and m0["rms"] == 0.0   # the reference's 1e-13 floor
