@@ -1,0 +1,263 @@
+// capi.cpp -- C ABI of libdrstencil_amd.so: generator-as-a-function, stencil IR
+// inspection, and the runtime that compiles emitted sources with hipcc for gfx950,
+// loads them and drives the reference's launch protocol on caller-owned device buffers.
+// See include/drstencil_amd.h for the reference interface each entry point stands for.
+#include "../../include/drstencil_amd.h"
+
+#include <dlfcn.h>
+#include <hip/hip_runtime_api.h>
+#include <sys/stat.h>
+#include <sys/types.h>
+#include <unistd.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "generator.hpp"
+
+using namespace drs;
+
+struct drs_spec {
+    Stencil st;
+};
+
+struct drs_kernel {
+    void *dl = nullptr;
+    int (*launch)(const void *, void *, hipStream_t) = nullptr;
+    int (*launch_gold)(const void *, void *, hipStream_t) = nullptr;
+    const char *(*info)(void) = nullptr;
+    std::string path;
+    int step = 1;
+};
+
+static char *dup_cstr(const std::string &s) {
+    char *p = (char *)malloc(s.size() + 1);
+    if (p) memcpy(p, s.c_str(), s.size() + 1);
+    return p;
+}
+
+static std::vector<std::string> to_args(int argc, const char *const *argv) {
+    std::vector<std::string> a;
+    for (int i = 0; i < argc; i++) a.push_back(argv[i] ? argv[i] : "");
+    return a;
+}
+
+extern "C" {
+
+const char *drs_version(void) { return "drstencil-amd 0.1 (gfx950)"; }
+
+void drs_free(void *p) { free(p); }
+
+int drs_generate(int argc, const char *const *argv, char **source, char **messages) {
+    GenResult r = generate(to_args(argc, argv));
+    if (source) *source = r.emitted ? dup_cstr(r.source) : nullptr;
+    if (messages) *messages = dup_cstr(r.messages);
+    return r.exit_code;
+}
+
+// ---- stencil IR -------------------------------------------------------------------------
+drs_spec *drs_spec_open(const char *stc_path, int ndim, int step, int dist, int merge_forward, int *status) {
+    drs_spec *s = new drs_spec();
+    s->st.ndim = ndim;
+    int rc = 0;
+    if (s->st.read_stc(stc_path) != 0) { delete s; if (status) *status = 1; return nullptr; }
+    s->st.fuse(step < 1 ? 1 : step);
+    s->st.choose_halo_dist(dist);
+    if (s->st.partition_reuse(merge_forward) != REUSE_OK) rc = 2;
+    s->st.stream_range();
+    if (status) *status = rc;
+    return s;
+}
+void drs_spec_close(drs_spec *s) { delete s; }
+int drs_spec_halo(const drs_spec *s) { return s->st.halo; }
+int drs_spec_dist(const drs_spec *s) { return s->st.dist; }
+int drs_spec_range(const drs_spec *s) { return s->st.range(); }
+int drs_spec_npoints(const drs_spec *s) { return (int)s->st.pts.size(); }
+int drs_spec_iterations(const drs_spec *s) { return s->st.iterations; }
+int drs_spec_launches(const drs_spec *s) { return s->st.launches(); }
+void drs_spec_dims(const drs_spec *s, int *L, int *M, int *N) { if (L) *L = s->st.L; if (M) *M = s->st.M; if (N) *N = s->st.N; }
+int drs_spec_point(const drs_spec *s, int idx, int *k, int *j, int *i, double *coef, char *coef_text_out) {
+    if (idx < 0 || idx >= (int)s->st.pts.size()) return -1;
+    const auto &e = s->st.pts.v[idx];
+    if (k) *k = e.first.k;
+    if (j) *j = e.first.j;
+    if (i) *i = e.first.i;
+    if (coef) *coef = coef_rounded(e.second);
+    if (coef_text_out) { std::string t = coef_text(e.second); strncpy(coef_text_out, t.c_str(), 31); coef_text_out[31] = 0; }
+    return 0;
+}
+void drs_spec_partition(const drs_spec *s, int sizes[4]) {
+    sizes[0] = (int)s->st.fwd_k.size(); sizes[1] = (int)s->st.fwd_j.size();
+    sizes[2] = (int)s->st.fwd_i.size(); sizes[3] = (int)s->st.bwd.size();
+}
+
+// ---- runtime ------------------------------------------------------------------------------
+static std::string self_dir() {
+    Dl_info di;
+    if (dladdr((void *)&drs_version, &di) && di.dli_fname) {
+        std::string p = di.dli_fname;
+        size_t s = p.find_last_of('/');
+        return s == std::string::npos ? "." : p.substr(0, s);
+    }
+    return ".";
+}
+
+static unsigned long long fnv1a(const std::string &s) {
+    unsigned long long h = 1469598103934665603ULL;
+    for (unsigned char c : s) { h ^= c; h *= 1099511628211ULL; }
+    return h;
+}
+
+static bool file_exists(const std::string &p) { struct stat sb; return stat(p.c_str(), &sb) == 0 && sb.st_size > 0; }
+
+static std::string run_capture(const std::string &cmd, int *rc) {
+    std::string out;
+    FILE *f = popen((cmd + " 2>&1").c_str(), "r");
+    if (!f) { *rc = -1; return "popen failed"; }
+    char buf[4096];
+    size_t n;
+    while ((n = fread(buf, 1, sizeof buf, f)) > 0) out.append(buf, n);
+    int st = pclose(f);
+    *rc = (st == -1) ? -1 : WEXITSTATUS(st);
+    return out;
+}
+
+drs_kernel *drs_kernel_build(int argc, const char *const *argv, const char *cache_dir, char **log) {
+    if (log) *log = nullptr;
+    GenResult r = generate(to_args(argc, argv));
+    if (!r.emitted) {
+        if (log) *log = dup_cstr(r.messages + (r.plan.error.empty() ? "" : ("drstencil: " + r.plan.error + "\n")));
+        return nullptr;
+    }
+    const std::string here = self_dir();
+    const std::string support = here + "/csrc/support";
+    std::string cdir = cache_dir ? cache_dir : (getenv("DRS_KCACHE") ? getenv("DRS_KCACHE") : here + "/_kcache");
+    mkdir(cdir.c_str(), 0777);
+    const char *hipcc_env = getenv("DRS_HIPCC");
+    const std::string hipcc = hipcc_env ? hipcc_env : "/opt/rocm/bin/hipcc";
+    const std::string flags = "-O3 --offload-arch=gfx950 -std=c++17 -ffp-contract=off -shared -fPIC -DDRS_PLUGIN";
+    // the key covers everything that determines the binary except the banner lines
+    std::string body = r.source.substr(r.source.find("#include"));
+    char key[64];
+    snprintf(key, sizeof key, "%s_%016llx", r.plan.name.c_str(), fnv1a(body + flags));
+    const std::string src = cdir + "/" + key + ".hip", so = cdir + "/" + key + ".so";
+    if (!file_exists(so)) {
+        char tmpl[64];
+        snprintf(tmpl, sizeof tmpl, ".%d.tmp", (int)getpid());
+        const std::string tsrc = src + tmpl + ".hip", tso = so + tmpl;
+        if (!write_text(tsrc, r.source)) { if (log) *log = dup_cstr("cannot write " + tsrc + "\n"); return nullptr; }
+        int rc = 0;
+        std::string out = run_capture(hipcc + " " + flags + " -I" + support + " -o " + tso + " " + tsrc, &rc);
+        if (rc != 0 || !file_exists(tso)) {
+            if (log) *log = dup_cstr("hipcc failed (" + std::to_string(rc) + "):\n" + out);
+            unlink(tso.c_str());
+            return nullptr;
+        }
+        rename(tsrc.c_str(), src.c_str());
+        rename(tso.c_str(), so.c_str());
+    }
+    void *dl = dlopen(so.c_str(), RTLD_NOW | RTLD_LOCAL);
+    if (!dl) { if (log) *log = dup_cstr(std::string("dlopen failed: ") + dlerror() + "\n"); return nullptr; }
+    drs_kernel *k = new drs_kernel();
+    k->dl = dl;
+    k->launch = (int (*)(const void *, void *, hipStream_t))dlsym(dl, "drs_plugin_launch");
+    k->launch_gold = (int (*)(const void *, void *, hipStream_t))dlsym(dl, "drs_plugin_launch_gold");
+    k->info = (const char *(*)(void))dlsym(dl, "drs_plugin_info");
+    k->path = so;
+    k->step = r.st.step;
+    if (!k->launch || !k->launch_gold || !k->info) {
+        if (log) *log = dup_cstr("plugin " + so + " lacks the drs_plugin_* entry points\n");
+        dlclose(dl);
+        delete k;
+        return nullptr;
+    }
+    return k;
+}
+
+void drs_kernel_close(drs_kernel *k) {
+    if (!k) return;
+    // the code object stays registered with the HIP runtime; leave the library mapped
+    delete k;
+}
+const char *drs_kernel_info(const drs_kernel *k) { return k->info(); }
+const char *drs_kernel_path(const drs_kernel *k) { return k->path.c_str(); }
+
+int drs_kernel_launch(drs_kernel *k, const void *d_in, void *d_out, void *stream) {
+    return k->launch(d_in, d_out, (hipStream_t)stream);
+}
+int drs_kernel_launch_gold(drs_kernel *k, const void *d_in, void *d_out, void *stream) {
+    return k->launch_gold(d_in, d_out, (hipStream_t)stream);
+}
+
+int drs_kernel_run(drs_kernel *k, void *d_a, void *d_b, int iterations, int gold, void *stream) {
+    auto fn = gold ? k->launch_gold : k->launch;
+    int n = 0;
+    for (int t = 0; t < iterations; t += 2 * k->step) {
+        if (fn(d_a, d_b, (hipStream_t)stream) != 0) return -1;
+        if (fn(d_b, d_a, (hipStream_t)stream) != 0) return -1;
+        n += 2;
+    }
+    return n;
+}
+
+int drs_kernel_run_timed(drs_kernel *k, void *d_a, void *d_b, int iterations, int warmup, void *stream, float *ms) {
+    hipStream_t s = (hipStream_t)stream;
+    for (int i = 0; i < warmup; i++)
+        if (k->launch(d_a, d_b, s) != 0) return -1;
+    hipEvent_t e0, e1;
+    if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return -1;
+    (void)hipEventRecord(e0, s);
+    int n = drs_kernel_run(k, d_a, d_b, iterations, 0, stream);
+    (void)hipEventRecord(e1, s);
+    hipError_t err = hipEventSynchronize(e1);
+    float t = 0.f;
+    if (err == hipSuccess) err = hipEventElapsedTime(&t, e0, e1);
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    if (ms) *ms = t;
+    return (err == hipSuccess) ? n : -1;
+}
+
+// ---- inputs and error metric (common.hpp:9-102) -----------------------------------------------
+void drs_fill_random_f64(double *a, size_t n, unsigned seed) {
+    srand(seed);
+    for (size_t x = 0; x < n; x++) a[x] = (double)rand() / (double)(RAND_MAX - 1);
+}
+void drs_fill_random_f32(float *a, size_t n, unsigned seed) {
+    srand(seed);
+    for (size_t x = 0; x < n; x++) a[x] = (float)((double)rand() / (double)(RAND_MAX - 1));
+}
+
+template <typename T>
+static double check_error(int ndim, int L, int M, int N, int H, const T *out, const T *ref, double *max_abs, long *max_idx, double *max_rel) {
+    const int klo = ndim == 3 ? H : 0, khi = ndim == 3 ? L - H : 1;
+    double err = 0.0, mx = 1e-13, mrel = 0.0;
+    long at = 0;
+    for (int k = klo; k < khi; k++)
+        for (int j = H; j < M - H; j++)
+            for (int i = H; i < N - H; i++) {
+                size_t x = ((size_t)k * M + j) * N + i;
+                double d = std::fabs((double)out[x] - (double)ref[x]);
+                err += d * d;
+                if (d > mx) { mx = d; at = (long)x; }
+                double r = std::fabs((double)ref[x]);
+                double rel = d / (r > 1e-30 ? r : 1e-30);
+                if (rel > mrel) mrel = rel;
+            }
+    if (max_abs) *max_abs = mx;
+    if (max_idx) *max_idx = at;
+    if (max_rel) *max_rel = mrel;
+    return std::sqrt(err / ((double)(khi - klo) * (double)(M - 2 * H) * (double)(N - 2 * H)));
+}
+double drs_check_error_f64(int ndim, int L, int M, int N, int halo, const double *out, const double *ref, double *max_abs, long *max_idx, double *max_rel) {
+    return check_error<double>(ndim, L, M, N, halo, out, ref, max_abs, max_idx, max_rel);
+}
+double drs_check_error_f32(int ndim, int L, int M, int N, int halo, const float *out, const float *ref, double *max_abs, long *max_idx, double *max_rel) {
+    return check_error<float>(ndim, L, M, N, halo, out, ref, max_abs, max_idx, max_rel);
+}
+
+}  // extern "C"

@@ -1,0 +1,169 @@
+// generator.hpp -- the `drstencil` command as a function: argv -> (messages, exit code,
+// emitted source).  Option surface, defaults, messages and exit codes follow the
+// reference's main.cpp:10-280 (hand-rolled scan 118-230: the last argument is always the
+// .stc; a value-taking flag in the second-to-last slot is "Illegal input." exit 255; an
+// unknown flag is "Illegal input." exit 0; `-o` without a value is ignored), plus
+// additive MI355X options that the reference does not have.
+#pragma once
+#include <fstream>
+#include <string>
+#include <vector>
+#include "emit_hip.hpp"
+#include "planner.hpp"
+#include "stencil_ir.hpp"
+
+namespace drs {
+
+struct GenResult {
+    int exit_code = 0;
+    std::string messages;   // what the command prints on stdout
+    std::string source;     // emitted HIP source (empty when nothing was emitted)
+    std::string out_name;
+    bool emitted = false;
+    Stencil st;
+    KernelPlan plan;
+    GenOptions opt;
+};
+
+inline const char *help_text() {
+    return R"(
+    Generate data-reusing stencil kernels for AMD Instinct MI355X (gfx950, HIP).
+
+    Usage: drstencil [options] <input_stcfile>
+Options:
+
+-o <file>               Specify the name of the output HIP source file.
+                        (out.cu by default)
+
+--3d                    Choose 3D mode.
+
+--step <num>            Specify the number of time steps to fuse the stencil.
+                        (step_num = 1 by default)
+
+--dist <num>            Specify the number of the distance between points for data-reuse.
+
+--streaming             Apply streaming optimization (2D; 3D always streams).
+
+--bx <num>              Specify the workgroup size bx (lanes along x; 64 = one wavefront).
+
+--by <num>              Specify the workgroup size by (rows of lanes along y).
+
+--sn <num>              Specify the length of stream block sn.
+
+--stream-unroll <num>   Specify the (minimum) unroll factor of the streaming loop.
+                        (stream_unroll = 4 by default)
+
+--block-merge-x <num>   Specify the number of contiguous points per lane along dimension x.
+
+--block-merge-y <num>   Specify the number of adjacent rows per lane along dimension y.
+
+--cyclic-merge-x <num>  Specify the number of points per lane along dimension x (laid out contiguously).
+
+--cyclic-merge-y <num>  Specify the number of rows per lane along dimension y, by rows apart.
+
+--prefetch              Prefetch the next plane into registers to hide the transfer latency.
+
+--merge-forward <num>   Specify the threshold for whether to merge the forward_j or forward_i into backward.
+                        (merge_forward = 5 by default)
+
+--check                 Check the correctness of the generated code against the gold kernel.
+
+--gold                  Accepted for compatibility (no effect).
+
+MI355X options:
+
+--dtype <fp32|fp64>     Element type (fp64 by default, as the reference).
+--xrim <lds|dpp>        x halo inside a wavefront through LDS or by DPP wave shifts.
+--lazy-rims <0|1>       Read LDS rims when first needed (1) or when a plane arrives (0).
+--xcd-remap <0|1>       XCD-aware workgroup to tile mapping (1 by default).
+--nt-store <0|1>        Non-temporal stores of the output.
+--nt-load <0|1>         Non-temporal loads of the input.
+--waves-per-eu <num>    Second argument of __launch_bounds__.
+--lds-pad <num>         Extra elements of padding per LDS row.
+--ref-defaults          Keep the reference's 16x16x16 geometry defaults.
+
+--help  (-h)            Print this help information on this tool.
+        )";
+}
+
+inline GenResult generate(const std::vector<std::string> &args /* argv[1..] */) {
+    GenResult res;
+    GenOptions &o = res.opt;
+    const int argc = (int)args.size() + 1;
+    auto arg = [&](int i) -> const std::string & { return args[i - 1]; };
+    if (argc < 2) { res.messages = "Please specify the .stc file.\n"; return res; }
+    if (arg(1) == "--help" || arg(1) == "-h") { res.messages = std::string(help_text()) + "\n"; return res; }
+
+    bool illegal_exit = false;
+    for (int i = 1; i < argc - 1; i++) {
+        const std::string &a = arg(i);
+        auto int_opt = [&](int &dst, bool *flag) -> bool {
+            if (i != argc - 2) { dst = atoi(arg(++i).c_str()); if (flag) *flag = true; return true; }
+            res.messages += "Illegal input.\n"; res.exit_code = 255; illegal_exit = true; return false;
+        };
+        auto str_opt = [&](std::string &dst) -> bool {
+            if (i != argc - 2) { dst = arg(++i); return true; }
+            res.messages += "Illegal input.\n"; res.exit_code = 255; illegal_exit = true; return false;
+        };
+        if (a == "-o") { if (i != argc - 2) { o.out_name = arg(++i); o.out_set = true; } }
+        else if (a == "--3d") o.is3d = true;
+        else if (a == "--step") { if (!int_opt(o.step, nullptr)) break; }
+        else if (a == "--dist") { if (!int_opt(o.dist, nullptr)) break; }
+        else if (a == "--streaming") o.streaming = true;
+        else if (a == "--bx") { if (!int_opt(o.bx, &o.bx_set)) break; }
+        else if (a == "--by") { if (!int_opt(o.by, &o.by_set)) break; }
+        else if (a == "--sn") { if (!int_opt(o.sn, &o.sn_set)) break; }
+        else if (a == "--block-merge-x") { if (!int_opt(o.bmx, &o.mx_set)) break; }
+        else if (a == "--block-merge-y") { if (!int_opt(o.bmy, &o.my_set)) break; }
+        else if (a == "--cyclic-merge-x") { if (!int_opt(o.cmx, &o.mx_set)) break; }
+        else if (a == "--cyclic-merge-y") { if (!int_opt(o.cmy, &o.my_set)) break; }
+        else if (a == "--stream-unroll") { if (!int_opt(o.stream_unroll, nullptr)) break; }
+        else if (a == "--prefetch") o.prefetch = true;
+        else if (a == "--merge-forward") { if (!int_opt(o.merge_forward, nullptr)) break; }
+        else if (a == "--check") o.check = true;
+        else if (a == "--gold") o.gold = true;
+        // ---- additive options
+        else if (a == "--dtype") { if (!str_opt(o.dtype)) break; }
+        else if (a == "--xrim") { if (!str_opt(o.xrim)) break; }
+        else if (a == "--lazy-rims") { if (!int_opt(o.lazy_rims, nullptr)) break; }
+        else if (a == "--xcd-remap") { if (!int_opt(o.xcd_remap, nullptr)) break; }
+        else if (a == "--nt-store") { if (!int_opt(o.nt_store, nullptr)) break; }
+        else if (a == "--nt-load") { if (!int_opt(o.nt_load, nullptr)) break; }
+        else if (a == "--waves-per-eu") { if (!int_opt(o.waves_per_eu, nullptr)) break; }
+        else if (a == "--lds-pad") { if (!int_opt(o.lds_pad, nullptr)) break; }
+        else if (a == "--ref-defaults") o.ref_defaults = 1;
+        else { res.messages += "Illegal input.\n"; res.exit_code = 0; return res; }
+    }
+    if (illegal_exit) return res;
+    if (o.dtype != "fp32" && o.dtype != "fp64") { res.messages += "Illegal input.\n"; res.exit_code = 255; return res; }
+    if (o.xrim != "lds" && o.xrim != "dpp") { res.messages += "Illegal input.\n"; res.exit_code = 255; return res; }
+    if (o.step < 1) { res.messages += "Illegal input.\n"; res.exit_code = 255; return res; }
+
+    const std::string &stcfile = arg(argc - 1);
+    Stencil &st = res.st;
+    st.ndim = o.is3d ? 3 : 2;
+    if (st.read_stc(stcfile) != 0) { res.messages += "Error opening stencil file.\n"; res.exit_code = 255; return res; }
+    st.fuse(o.step);
+    st.choose_halo_dist(o.dist);
+    if (st.partition_reuse(o.merge_forward) != REUSE_OK) { res.messages += "No data to reuse. You can try another dist.\n"; res.exit_code = 1; return res; }
+    st.stream_range();
+
+    res.plan = make_plan(st, o, kernel_base_name(stcfile));
+    if (!res.plan.error.empty()) { res.messages += "Invalid configuration!\n"; res.exit_code = 255; return res; }
+    std::string cmdline;
+    for (size_t i = 0; i + 1 < args.size(); i++) cmdline += (i ? " " : "") + args[i];
+    HipEmitter em(res.plan, o);
+    res.source = em.source(stcfile, cmdline);
+    res.out_name = o.out_name;
+    res.emitted = true;
+    return res;
+}
+
+inline bool write_text(const std::string &path, const std::string &text) {
+    std::ofstream f(path, std::ios::out | std::ios::trunc);
+    if (!f) return false;
+    f << text;
+    return (bool)f;
+}
+
+}  // namespace drs

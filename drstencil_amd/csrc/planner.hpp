@@ -1,0 +1,119 @@
+// planner.hpp -- turns (Stencil, GenOptions) into a KernelPlan: role mapping of the
+// dims, tile geometry, LDS layout and the validity checks.
+//
+// Reference behaviour kept: block-vs-cyclic resolution and merge factors
+// (main.cpp:232-235), the "Invalid configuration!" test (codegen.hpp:50-55,
+// codegen_2d.hpp:52-57), --streaming ignored in 3D and --by / y-merge ignored by
+// the 2D streaming kernel (codegen_2d.hpp:125).
+#pragma once
+#include <algorithm>
+#include <string>
+#include "plan.hpp"
+
+namespace drs {
+
+inline std::string kernel_base_name(const std::string &stc_path) {
+    // reference: path minus its last 4 characters (main.cpp:243-244), so the .stc has
+    // to sit in the cwd; we additionally drop directories and sanitise to an identifier.
+    std::string s = stc_path;
+    size_t slash = s.find_last_of('/');
+    if (slash != std::string::npos) s = s.substr(slash + 1);
+    if (s.size() >= 4) s.erase(s.size() - 4);
+    for (auto &c : s) if (!(isalnum((unsigned char)c) || c == '_')) c = '_';
+    if (s.empty() || isdigit((unsigned char)s[0])) s = "s" + s;
+    return s;
+}
+
+// true when the reference would print "Invalid configuration!" (exit 255)
+inline bool reference_invalid(const Stencil &st, const GenOptions &o, int mx, int my) {
+    int halo2 = st.halo * 2;
+    bool fi = st.fwd_i.size() > 0, fj = st.fwd_j.size() > 0;
+    if (st.ndim == 3) return (halo2 >= o.bx * mx && fi) || (halo2 >= o.by * my && fj);
+    // 2D (codegen_2d.hpp:52-56): only the x extent is tested
+    (void)fj; (void)my;
+    return halo2 >= o.bx * mx && fi;
+}
+
+inline KernelPlan make_plan(const Stencil &st, const GenOptions &o_in, const std::string &name) {
+    GenOptions o = o_in;
+    KernelPlan p;
+    p.name = name;
+    p.ndim = st.ndim;
+    p.fp32 = (o.dtype == "fp32");
+    p.L = st.L; p.M = st.M; p.N = st.N;
+    p.iterations = st.iterations; p.step = st.step; p.halo = st.halo; p.dist = st.dist; p.range = st.range();
+    p.prefetch = o.prefetch;
+
+    const bool stream2d = (st.ndim == 2 && o.streaming);
+    p.has_s = (st.ndim == 3) || stream2d;
+    p.has_y = (st.ndim == 3) || !stream2d;
+
+    // MI355X defaults for whatever geometry the user left unset: one wavefront (64
+    // lanes) along x with 16-byte accesses per lane.
+    const int vec_elems = p.fp32 ? 4 : 2;
+    if (!o.ref_defaults) {
+        if (!o.bx_set) o.bx = 64;
+        if (!o.mx_set) { o.bmx = vec_elems; o.cmx = 1; }
+        if (!o.by_set) o.by = p.has_y ? 4 : 1;
+        if (!o.my_set && p.has_y) { o.bmy = (st.ndim == 3) ? 4 : 8; o.cmy = 1; }
+        if (!o.sn_set) o.sn = 64;
+    }
+    const bool bmerge_y = o.bmy > o.cmy;
+    const int mx = std::max(o.bmx, o.cmx), my = std::max(o.bmy, o.cmy);
+
+    // role mapping (streamed, row, col)
+    for (auto &e : st.pts.v) {
+        Tap t;
+        if (st.ndim == 3) { t.ds = e.first.k; t.dy = e.first.j; t.dx = e.first.i; }
+        else if (stream2d) { t.ds = e.first.j; t.dy = 0; t.dx = e.first.i; }
+        else { t.ds = 0; t.dy = e.first.j; t.dx = e.first.i; }
+        t.coef = coef_text(e.second);
+        p.taps.push_back(t);
+        p.zl = std::min(p.zl, t.ds); p.zh = std::max(p.zh, t.ds);
+        p.hym = std::max(p.hym, -t.dy); p.hyp = std::max(p.hyp, t.dy);
+        p.hxm = std::max(p.hxm, -t.dx); p.hxp = std::max(p.hxp, t.dx);
+    }
+    if (st.ndim == 3) { p.DS = st.L; p.DY = st.M; p.DX = st.N; p.stride_s = (long)st.M * st.N; p.stride_y = st.N; }
+    else if (stream2d) { p.DS = st.M; p.DY = 1; p.DX = st.N; p.stride_s = st.N; p.stride_y = 0; }
+    else { p.DS = 1; p.DY = st.M; p.DX = st.N; p.stride_s = 0; p.stride_y = st.N; }
+
+    if (p.taps.empty()) { p.error = "empty stencil"; return p; }
+    if (st.M <= 0 || st.N <= 0 || (st.ndim == 3 && st.L <= 0)) { p.error = "grid size missing in the .stc"; return p; }
+    // The interior guard is Halo in every dim (codegen.hpp:654); a tap reaching further
+    // than Halo would read outside the arrays in the reference.
+    if (std::max({-p.zl, p.zh, p.hym, p.hyp, p.hxm, p.hxp}) > st.halo) { p.error = "a tap reaches beyond Halo (outermost-dim order)"; return p; }
+    // evaluated on the options as given (reference defaults for the unset ones), so the
+    // error behaviour is the reference's own
+    if (reference_invalid(st, o_in, std::max(o_in.bmx, o_in.cmx), std::max(o_in.bmy, o_in.cmy))) { p.error = "tile does not cover the halo"; return p; }
+
+    p.BX = o.bx; p.VX = mx;
+    p.BY = p.has_y ? o.by : 1;
+    p.RY = p.has_y ? my : 1;
+    p.cyclic_y = p.has_y && !bmerge_y && my > 1;
+    p.SN = p.has_s ? std::max(1, o.sn) : 1;
+    p.NT = p.BX * p.BY;
+    if (p.BX < 1 || p.BY < 1 || p.NT > 1024) { p.error = "workgroup must have 1..1024 threads"; return p; }
+
+    // vector width of memory accesses: 16 bytes when rows stay 16-byte aligned
+    int vl = p.fp32 ? 4 : 2;
+    while (vl > 1 && (p.VX % vl != 0 || st.N % vl != 0)) vl >>= 1;
+    p.VL = vl; p.NV = p.VX / vl;
+    p.TX = p.BX * p.VX;
+    p.TY = p.BY * p.RY;
+    p.PADL = p.hxm ? round_up(p.hxm, vl) : 0;
+    p.PADR = p.hxp ? round_up(p.hxp, vl) : 0;
+    p.OY = p.has_y ? p.TY - p.hym - p.hyp : 1;
+    if (p.OY < 1) { p.error = "tile has no rows left after the y halo"; return p; }
+    if (p.PADL > p.TX || p.PADR > p.TX) { p.error = "x halo wider than the tile"; return p; }
+    const int H = st.halo;
+    p.NBX = std::max(1, ceil_div(p.DX - H, p.TX));
+    p.NBY = p.has_y ? std::max(1, ceil_div(p.DY - H, p.OY)) : 1;
+    p.NBS = p.has_s ? std::max(1, ceil_div(p.DS - 2 * H, p.SN)) : 1;
+    if (p.DX - 2 * H < 1 || (p.has_y && p.DY - 2 * H < 1) || (p.has_s && p.DS - 2 * H < 1)) { p.error = "grid has no interior"; return p; }
+
+    p.SROW = p.PADL + p.TX + p.PADR + o.lds_pad;
+    p.SROWS = p.has_y ? p.TY + p.hym + p.hyp : 1;
+    return p;
+}
+
+}  // namespace drs

@@ -1,0 +1,81 @@
+/*
+ * drstencil_amd.h -- C ABI of libdrstencil_amd.so (MI355X-native DRStencil generator + runtime).
+ *
+ * The reference (simple86/DRStencil) has NO library/FFI surface: its boundary is the
+ * `drstencil` command line, the .stc file format and the emitted program.
+ * Each entry point below names the reference interface it stands for; INTEGRATION.md shows
+ * how a maintainer binds it.  Plain C types only; device buffers are raw device pointers
+ * (e.g. torch.Tensor.data_ptr()), streams are hipStream_t passed as void*.
+ */
+#ifndef DRSTENCIL_AMD_H
+#define DRSTENCIL_AMD_H
+#include <stddef.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct drs_spec drs_spec;     /* parsed + fused stencil, reuse analysis done */
+typedef struct drs_kernel drs_kernel; /* generated, compiled (hipcc, gfx950) and loaded kernel */
+
+/* ---- generator: the `drstencil [options] file.stc` command as a function.
+ * Replaces main() of main.cpp:10-280 (option scan 118-230, pipeline 237-278).
+ * argv excludes the program name.  Returns the process exit code the command would have
+ * (0, 1 "No data to reuse", 255 "Illegal input."/"Invalid configuration!"/"Error opening
+ * stencil file.").  *source (emitted HIP text, NULL if nothing was emitted) and *messages
+ * (stdout text) are malloc'ed; release with drs_free.  No file is written. */
+int drs_generate(int argc, const char *const *argv, char **source, char **messages);
+void drs_free(void *p);
+
+/* ---- stencil IR: DRStencil / DRStencil_2d (drstencil.hpp:15-49, drstencil_2d.hpp).
+ * drs_spec_open = get_stencil (52-78) + fusing (262-282) + dataReuse (306-311).
+ * *status: 0 ok, 1 cannot open the file, 2 "No data to reuse" (spec still returned). */
+drs_spec *drs_spec_open(const char *stc_path, int ndim, int step, int dist, int merge_forward, int *status);
+void drs_spec_close(drs_spec *s);
+int drs_spec_halo(const drs_spec *s);        /* get_order()    drstencil.hpp:34 */
+int drs_spec_dist(const drs_spec *s);        /* get_distance() drstencil.hpp:35 */
+int drs_spec_range(const drs_spec *s);       /* high_k - low_k + 1, codegen.hpp:89 */
+int drs_spec_npoints(const drs_spec *s);     /* fused stencil size */
+int drs_spec_iterations(const drs_spec *s);  /* get_problem_size, drstencil.hpp:80-86 */
+int drs_spec_launches(const drs_spec *s);    /* kernel launches of the timed loop, codegen.hpp:581-584 */
+void drs_spec_dims(const drs_spec *s, int *L, int *M, int *N);
+/* point idx in gold (lexicographic) order; coef_text = the 6-significant-digit literal
+ * the emitted source carries (drstencil.hpp:192), at least 32 bytes */
+int drs_spec_point(const drs_spec *s, int idx, int *k, int *j, int *i, double *coef, char *coef_text);
+/* sizes of forward_k, forward_j, forward_i, backward (partition, drstencil.hpp:198-259) */
+void drs_spec_partition(const drs_spec *s, int sizes[4]);
+
+/* ---- runtime: what the emitted program's main() does (host_code_gen, codegen.hpp:547-635),
+ * callable on caller-owned device buffers.
+ * drs_kernel_build: generate (same argv as drs_generate), compile with hipcc for gfx950 into
+ * cache_dir (NULL: <package>/_kcache) unless already cached, and load.  NULL on failure with
+ * *log (malloc'ed, may be NULL) holding the generator messages / compiler output. */
+drs_kernel *drs_kernel_build(int argc, const char *const *argv, const char *cache_dir, char **log);
+void drs_kernel_close(drs_kernel *k);
+const char *drs_kernel_info(const drs_kernel *k);   /* JSON: dims, dtype, halo, step, grid, lds ... */
+const char *drs_kernel_path(const drs_kernel *k);   /* the loaded shared object */
+/* one launch of dr_<name><<<grid, block, 0, stream>>>(in, out): codegen.hpp:577,582-583 */
+int drs_kernel_launch(drs_kernel *k, const void *d_in, void *d_out, void *stream);
+/* one launch of gold_<name> (the reference's verification kernel, codegen.hpp:611-612) */
+int drs_kernel_launch_gold(drs_kernel *k, const void *d_in, void *d_out, void *stream);
+/* the timed ping-pong loop: for (t = 0; t < iterations; t += 2*step) { k(A,B); k(B,A); }
+ * (codegen.hpp:581-584).  gold != 0 runs gold_<name> instead.  Returns the number of
+ * launches, or -1 on a HIP error.  Asynchronous on `stream`. */
+int drs_kernel_run(drs_kernel *k, void *d_a, void *d_b, int iterations, int gold, void *stream);
+/* `warmup` untimed launches (A,B) (codegen.hpp:575-578), then the loop above bracketed by
+ * HIP events recorded on `stream`; blocks until done; *ms = elapsed milliseconds. */
+int drs_kernel_run_timed(drs_kernel *k, void *d_a, void *d_b, int iterations, int warmup, void *stream, float *ms);
+
+/* ---- inputs and error metric: common.hpp:9-102 (host memory) */
+void drs_fill_random_f64(double *a, size_t n, unsigned seed);   /* seed 1 == the reference's unseeded rand() */
+void drs_fill_random_f32(float *a, size_t n, unsigned seed);
+double drs_check_error_f64(int ndim, int L, int M, int N, int halo, const double *out, const double *ref,
+                           double *max_abs, long *max_idx, double *max_rel);
+double drs_check_error_f32(int ndim, int L, int M, int N, int halo, const float *out, const float *ref,
+                           double *max_abs, long *max_idx, double *max_rel);
+
+const char *drs_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
