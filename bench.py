@@ -1,0 +1,220 @@
+#!/usr/bin/env python3
+"""bench.py -- the north-star measurement (BASELINE.json): GStencil/s and achieved HBM GB/s
+vs the MI355X roofline on 3d7pt_star, fp32.
+
+    python bench.py --gpus N --steps K --warmup W
+
+Workload (config.workload): C4 = 3d7pt_star 1024^3 fp32, `iterations 4` (the configuration
+the metric is quoted on; 8 GiB for the two buffers, fits one GPU).  One "step" = the
+reference's timed region (codegen.hpp:581-584): the ping-pong loop over the .stc's 4 time
+steps = 2*ceil(4/(2*step)) kernel launches.  N > 1: the same 1024^3 grid cut into z slabs,
+one process per GPU, RCCL halo exchange overlapped with the interior sweep (strong scaling).
+
+value      = grid-point updates of all ranks / max-over-ranks wall time, in GStencil/s
+roofline   = algorithmic bytes (2*sizeof(T) per grid point per launch)
+             / average launch duration measured with HIP events on the launch stream
+cpu_baseline = the CPU oracle (oracle/, OpenMP) on a bounded z-slab sample of the same workload
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+CFG = os.path.join(ROOT, "benchmarks", "configs")
+WORKLOADS = {
+    "c4": dict(stc=os.path.join(CFG, "c4_3d7pt_star_1024.stc"), ndim=3, dtype="fp32", name="3d7pt_star 1024^3 fp32 (BASELINE C4), iterations 4"),
+    "c3": dict(stc=os.path.join(CFG, "c3_3d7pt_star_512.stc"), ndim=3, dtype="fp32", name="3d7pt_star 512^3 fp32 (BASELINE C3), iterations 4"),
+    "c2": dict(stc=os.path.join(CFG, "c2_2d5pt_star_8192.stc"), ndim=2, dtype="fp32", name="2d5pt_star 8192^2 fp32 (BASELINE C2), iterations 4"),
+    "c5": dict(stc=os.path.join(CFG, "c5_2d25pt_box_16384.stc"), ndim=2, dtype="fp64", name="2d25pt_box 16384^2 fp64 (BASELINE C5), iterations 4"),
+}
+# tuned generator options per workload (see profiles/ and DESIGN.md; found with drstencil_amd/tuner)
+TUNED = {
+    "c4": ["--3d", "--dtype", "fp32"],
+    "c3": ["--3d", "--dtype", "fp32"],
+    "c2": ["--dtype", "fp32", "--streaming"],
+    "c5": ["--dtype", "fp64", "--streaming"],
+}
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak (MI355X_MICROARCH.md: 8.0 TB/s spec)
+
+
+def kernel_arg_sets():
+    """Kernels bench.py needs; prebuilt by __graft_entry__.build()."""
+    return [TUNED[w] + [WORKLOADS[w]["stc"]] for w in ("c4", "c3", "c2", "c5")]
+
+
+def cpu_baseline(workload, step, budget_s=20.0):
+    """Oracle (port) timed on the host cores on a bounded z/y-slab sample of the workload."""
+    import numpy as np
+    import oracle
+    w = WORKLOADS[workload]
+    spec = oracle.Spec(w["stc"], w["ndim"], step)
+    L, M, N = spec.dims
+    # bounded sample: a slab of the outermost dim (same plane size, same stencil, same dtype)
+    if w["ndim"] == 3:
+        Ls = min(L, 128)
+        spec.set_dims(Ls, M, N)
+        sample = "%d x %d x %d z-slab of the %d^3 grid" % (Ls, M, N, L)
+    else:
+        Ms = min(M, 4096)
+        spec.set_dims(1, Ms, N)
+        sample = "%d x %d y-slab" % (Ms, N)
+    dt = np.float32 if w["dtype"] == "fp32" else np.float64
+    rng = np.random.default_rng(1)
+    A = rng.random(spec.shape, dtype=dt)
+    B = np.zeros_like(A)
+    h = spec.halo
+    interior = 1
+    for d in spec.shape:
+        interior *= d - 2 * h
+    oracle.sweep(spec, A, B, 1)  # warm (page faults)
+    t0 = time.perf_counter()
+    sweeps = 0
+    while True:
+        oracle.sweep(spec, A, B, 1)
+        oracle.sweep(spec, B, A, 1)
+        sweeps += 2
+        el = time.perf_counter() - t0
+        if el > budget_s or sweeps >= 64:
+            break
+    gst = sweeps * step * interior / el / 1e9
+    return dict(value=gst, unit="GStencil/s", cores=oracle.threads(), kind="port",
+                sample="%s, %d sweeps in %.1f s (OpenMP, %d threads)" % (sample, sweeps, el, oracle.threads()))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="c4", choices=sorted(WORKLOADS))
+    ap.add_argument("--kernel-args", default=None, help="override the generator options (space separated)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import drstencil_amd as drs
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # Generate + compile (or find cached) every kernel BEFORE HIP is initialised: a process
+    # that has touched the GPU must not fork/exec the compiler.
+    w = WORKLOADS[args.workload]
+    opts = args.kernel_args.split() if args.kernel_args else TUNED[args.workload]
+    spec = drs.Spec(w["stc"], w["ndim"], int(opts[opts.index("--step") + 1]) if "--step" in opts else 1)
+    L, M, N = spec.dims
+    H, step, iters = spec.halo, spec.step, spec.iterations
+    if world == 1:
+        kern = drs.Kernel(opts + [w["stc"]])
+    else:
+        from drstencil_amd.multigpu import HipSweep, SlabPlan, SlabRun
+        assert w["ndim"] == 3, "slab decomposition is implemented for 3D specs"
+        sweep = HipSweep(w["stc"], opts, os.path.join(ROOT, "drstencil_amd", "_kcache"))
+        sp = SlabPlan(L, H, world, rank)
+        for v in (sp.top, sp.bot, sp.interior):
+            if v is not None and v[1] - v[0] > 2 * H:
+                sweep.kernel(v[1] - v[0])
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the product path has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    assert world == args.gpus or world == 1 and args.gpus == 1, "launch with torch.distributed.run for --gpus > 1"
+
+    tdt = torch.float32 if w["dtype"] == "fp32" else torch.float64
+    esz = 4 if w["dtype"] == "fp32" else 8
+    launches_per_step = spec.launches
+    interior = (M - 2 * H) * (N - 2 * H) * ((L - 2 * H) if w["ndim"] == 3 else 1)
+    npoints = M * N * (L if w["ndim"] == 3 else 1)
+
+    ev_ms = 0.0
+    if world == 1:
+        g = torch.Generator(device=dev).manual_seed(1)
+        shape = (L, M, N) if w["ndim"] == 3 else (M, N)
+        A = torch.rand(shape, dtype=tdt, device=dev, generator=g)
+        B = torch.zeros_like(A)
+        stream = torch.cuda.current_stream(dev)
+        for _ in range(args.warmup):
+            kern.run(A.data_ptr(), B.data_ptr(), stream=stream.cuda_stream)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t0 = time.perf_counter()
+        e0.record(stream)
+        n = 0
+        for _ in range(args.steps):
+            n += kern.run(A.data_ptr(), B.data_ptr(), stream=stream.cuda_stream)
+        e1.record(stream)
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+        ev_ms = e0.elapsed_time(e1)
+        assert n == launches_per_step * args.steps
+        kinfo = kern.info
+        parallelism = "1 GPU"
+    else:
+        run = SlabRun(torch, dist, L, M, N, H, step, iters, rank, world, sweep, dev, tdt)
+        g = torch.Generator(device=dev).manual_seed(1 + rank)
+        run.A.copy_(torch.rand(run.A.shape, dtype=tdt, device=dev, generator=g))
+        for _ in range(args.warmup):
+            run.run()
+        torch.cuda.synchronize()
+        dist.barrier()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t0 = time.perf_counter()
+        e0.record(run.main)
+        n = 0
+        for _ in range(args.steps):
+            n += run.run()
+        e1.record(run.main)
+        torch.cuda.synchronize()
+        dist.barrier()
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+        ev_ms = e0.elapsed_time(e1)
+        t = torch.tensor([el, ev_ms], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        el, ev_ms = float(t[0]), float(t[1])
+        kinfo = sweep.kernel(run.plan.interior[1] - run.plan.interior[0]).info
+        parallelism = "z-slab x%d, RCCL send/recv halo, overlapped" % world
+
+    if rank == 0:
+        total_launches = launches_per_step * args.steps
+        updates = total_launches * step * interior
+        value = updates / el / 1e9
+        # roofline of the dominant kernel dr_<name>: algorithmic bytes per launch / average
+        # launch duration from the HIP events around the timed launches
+        alg_bytes = 2.0 * esz * npoints / max(world, 1)     # per launch per GPU
+        avg_launch_s = (ev_ms * 1e-3) / total_launches
+        achieved = alg_bytes / avg_launch_s / 1e9
+        out = {
+            "metric": "GStencil/s (grid-point updates/s), 3d7pt_star" if args.workload in ("c3", "c4") else "GStencil/s (grid-point updates/s)",
+            "value": value, "unit": "GStencil/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": el * 1e3 / args.steps, "higher_is_better": True, "scaling": "strong",
+            "vs_baseline": None, "dtype": "f32" if w["dtype"] == "fp32" else "f64", "data": "synthetic",
+            "config": {"workload": w["name"], "generator_options": " ".join(opts), "step": step,
+                       "launches_per_step": launches_per_step, "parallelism": parallelism,
+                       "kernel": "dr_" + kinfo["name"], "threads": kinfo["threads"], "lds_bytes": kinfo["lds_bytes"]},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": avg_launch_s * 1e3},
+        }
+        if not args.no_cpu_baseline and world == 1:
+            sys.path.insert(0, ROOT)
+            out["cpu_baseline"] = cpu_baseline(args.workload, step)
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,241 @@
+"""drstencil_amd -- MI355X-native DRStencil: Python front end over libdrstencil_amd.so.
+
+The product is the C++ generator (`bin/drstencil`, emits HIP for gfx950) and the C-ABI
+runtime in libdrstencil_amd.so (include/drstencil_amd.h).  This module is the thin
+ctypes binding used by the tests, the tuner, bench.py and the multi-GPU driver.  It
+fails loudly when the native library is missing; there is no CPU or PyTorch fallback.
+"""
+import ctypes
+import json
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libdrstencil_amd.so")
+ROOT = os.path.dirname(_HERE)
+CLI_PATH = os.path.join(ROOT, "bin", "drstencil")
+SUPPORT_DIR = os.path.join(_HERE, "csrc", "support")
+BENCH_DIR = os.path.join(ROOT, "benchmarks")
+
+_lib = None
+
+
+class NativeLibraryMissing(RuntimeError):
+    pass
+
+
+def lib():
+    """Load libdrstencil_amd.so (built by `make -C drstencil_amd/csrc` / __graft_entry__.build())."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise NativeLibraryMissing(
+            "%s not found: build it with `make -C %s` (or __graft_entry__.build()); "
+            "drstencil_amd has no fallback path" % (LIB_PATH, os.path.join(_HERE, "csrc")))
+    L = ctypes.CDLL(LIB_PATH, mode=ctypes.RTLD_GLOBAL)
+    cpp = ctypes.POINTER(ctypes.c_char_p)
+    vp, ci = ctypes.c_void_p, ctypes.c_int
+    L.drs_version.restype = ctypes.c_char_p
+    L.drs_free.argtypes = [vp]
+    L.drs_generate.argtypes = [ci, cpp, ctypes.POINTER(vp), ctypes.POINTER(vp)]
+    L.drs_spec_open.restype = vp
+    L.drs_spec_open.argtypes = [ctypes.c_char_p, ci, ci, ci, ci, ctypes.POINTER(ci)]
+    L.drs_spec_close.argtypes = [vp]
+    for n in ("halo", "dist", "range", "npoints", "iterations", "launches"):
+        getattr(L, "drs_spec_" + n).argtypes = [vp]
+    L.drs_spec_dims.argtypes = [vp] + [ctypes.POINTER(ci)] * 3
+    L.drs_spec_point.argtypes = [vp, ci] + [ctypes.POINTER(ci)] * 3 + [ctypes.POINTER(ctypes.c_double), ctypes.c_char_p]
+    L.drs_spec_partition.argtypes = [vp, ctypes.POINTER(ci * 4)]
+    L.drs_kernel_build.restype = vp
+    L.drs_kernel_build.argtypes = [ci, cpp, ctypes.c_char_p, ctypes.POINTER(vp)]
+    L.drs_kernel_close.argtypes = [vp]
+    L.drs_kernel_info.restype = ctypes.c_char_p
+    L.drs_kernel_info.argtypes = [vp]
+    L.drs_kernel_path.restype = ctypes.c_char_p
+    L.drs_kernel_path.argtypes = [vp]
+    L.drs_kernel_launch.argtypes = [vp, vp, vp, vp]
+    L.drs_kernel_launch_gold.argtypes = [vp, vp, vp, vp]
+    L.drs_kernel_run.argtypes = [vp, vp, vp, ci, ci, vp]
+    L.drs_kernel_run_timed.argtypes = [vp, vp, vp, ci, ci, vp, ctypes.POINTER(ctypes.c_float)]
+    L.drs_fill_random_f64.argtypes = [vp, ctypes.c_size_t, ctypes.c_uint]
+    L.drs_fill_random_f32.argtypes = [vp, ctypes.c_size_t, ctypes.c_uint]
+    for n in ("drs_check_error_f64", "drs_check_error_f32"):
+        f = getattr(L, n)
+        f.restype = ctypes.c_double
+        f.argtypes = [ci] * 5 + [vp, vp, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_long), ctypes.POINTER(ctypes.c_double)]
+    _lib = L
+    return L
+
+
+EXPORTS = [
+    "drs_version", "drs_free", "drs_generate",
+    "drs_spec_open", "drs_spec_close", "drs_spec_halo", "drs_spec_dist", "drs_spec_range", "drs_spec_npoints",
+    "drs_spec_iterations", "drs_spec_launches", "drs_spec_dims", "drs_spec_point", "drs_spec_partition",
+    "drs_kernel_build", "drs_kernel_close", "drs_kernel_info", "drs_kernel_path", "drs_kernel_launch",
+    "drs_kernel_launch_gold", "drs_kernel_run", "drs_kernel_run_timed",
+    "drs_fill_random_f64", "drs_fill_random_f32", "drs_check_error_f64", "drs_check_error_f32",
+]
+
+
+def _argv(args):
+    arr = (ctypes.c_char_p * len(args))(*[os.fsencode(str(a)) for a in args])
+    return len(args), arr
+
+
+def _take(ptr):
+    if not ptr or not ptr.value:
+        return None
+    s = ctypes.string_at(ptr.value).decode()
+    lib().drs_free(ptr.value)
+    return s
+
+
+def generate(args):
+    """The `drstencil` command as a function (main.cpp:10-280): returns (exit_code, stdout, source|None)."""
+    n, arr = _argv(args)
+    src, msg = ctypes.c_void_p(), ctypes.c_void_p()
+    rc = lib().drs_generate(n, arr, ctypes.byref(src), ctypes.byref(msg))
+    return rc, _take(msg) or "", _take(src)
+
+
+class Spec:
+    """Parsed + fused stencil with reuse analysis (DRStencil / DRStencil_2d classes)."""
+
+    def __init__(self, stc_path, ndim, step=1, dist=0, merge_forward=5):
+        st = ctypes.c_int()
+        self.h = lib().drs_spec_open(os.fsencode(stc_path), ndim, step, dist, merge_forward, ctypes.byref(st))
+        self.status = st.value
+        if not self.h:
+            raise IOError("Error opening stencil file.")
+        self.ndim, self.step = ndim, step
+
+    def close(self):
+        if self.h:
+            lib().drs_spec_close(self.h)
+            self.h = None
+
+    __del__ = close
+
+    halo = property(lambda s: lib().drs_spec_halo(s.h))
+    dist = property(lambda s: lib().drs_spec_dist(s.h))
+    range = property(lambda s: lib().drs_spec_range(s.h))
+    npoints = property(lambda s: lib().drs_spec_npoints(s.h))
+    iterations = property(lambda s: lib().drs_spec_iterations(s.h))
+    launches = property(lambda s: lib().drs_spec_launches(s.h))
+
+    @property
+    def dims(self):
+        a, b, c = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+        lib().drs_spec_dims(self.h, a, b, c)
+        return a.value, b.value, c.value
+
+    @property
+    def shape(self):
+        return self.dims if self.ndim == 3 else self.dims[1:]
+
+    @property
+    def points(self):
+        out = []
+        k, j, i, c = ctypes.c_int(), ctypes.c_int(), ctypes.c_int(), ctypes.c_double()
+        buf = ctypes.create_string_buffer(32)
+        for p in range(self.npoints):
+            lib().drs_spec_point(self.h, p, k, j, i, c, buf)
+            out.append(((k.value, j.value, i.value), c.value, buf.value.decode()))
+        return out
+
+    @property
+    def partition(self):
+        a = (ctypes.c_int * 4)()
+        lib().drs_spec_partition(self.h, ctypes.byref(a))
+        return tuple(a)
+
+
+class KernelBuildError(RuntimeError):
+    pass
+
+
+class Kernel:
+    """A generated kernel: drstencil options -> HIP source -> hipcc (gfx950) -> loaded.
+
+    `args` are exactly the `drstencil` command-line arguments (ending with the .stc path).
+    Buffers are raw device pointers (ints), e.g. torch.Tensor.data_ptr()."""
+
+    def __init__(self, args, cache_dir=None):
+        n, arr = _argv(args)
+        log = ctypes.c_void_p()
+        self.h = lib().drs_kernel_build(n, arr, os.fsencode(cache_dir) if cache_dir else None, ctypes.byref(log))
+        msg = _take(log)
+        if not self.h:
+            raise KernelBuildError(msg or "kernel build failed")
+        self.info = json.loads(lib().drs_kernel_info(self.h).decode())
+        self.path = lib().drs_kernel_path(self.h).decode()
+        self.args = list(args)
+
+    def launch(self, d_in, d_out, stream=0):
+        rc = lib().drs_kernel_launch(self.h, d_in, d_out, stream)
+        if rc != 0:
+            raise RuntimeError("HIP launch error %d" % rc)
+
+    def launch_gold(self, d_in, d_out, stream=0):
+        rc = lib().drs_kernel_launch_gold(self.h, d_in, d_out, stream)
+        if rc != 0:
+            raise RuntimeError("HIP launch error %d" % rc)
+
+    def run(self, d_a, d_b, iterations=None, gold=False, stream=0):
+        """The reference's ping-pong loop (codegen.hpp:581-584); result ends in A."""
+        it = self.info["iterations"] if iterations is None else iterations
+        n = lib().drs_kernel_run(self.h, d_a, d_b, it, 1 if gold else 0, stream)
+        if n < 0:
+            raise RuntimeError("HIP error in drs_kernel_run")
+        return n
+
+    def run_timed(self, d_a, d_b, iterations=None, warmup=10, stream=0):
+        """Warm-up launches + timed loop bracketed by HIP events on `stream`: (launches, ms)."""
+        it = self.info["iterations"] if iterations is None else iterations
+        ms = ctypes.c_float()
+        n = lib().drs_kernel_run_timed(self.h, d_a, d_b, it, warmup, stream, ctypes.byref(ms))
+        if n < 0:
+            raise RuntimeError("HIP error in drs_kernel_run_timed")
+        return n, ms.value
+
+    # work / traffic model
+    def updates_per_launch(self):
+        i = self.info
+        h = i["halo"]
+        dims = [i["L"], i["M"], i["N"]] if i["ndim"] == 3 else [i["M"], i["N"]]
+        n = 1
+        for d in dims:
+            n *= d - 2 * h
+        return n * i["step"]
+
+    def bytes_per_launch(self):
+        i = self.info
+        pts = i["M"] * i["N"] * (i["L"] if i["ndim"] == 3 else 1)
+        return 2 * (4 if i["dtype"] == "fp32" else 8) * pts
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib().drs_kernel_close(self.h)
+            self.h = None
+
+    __del__ = close
+
+
+def fill_random(arr, seed=1):
+    """common.hpp:9-32 input stream into a numpy array (in place)."""
+    import numpy as np
+    fn = {np.dtype("float64"): lib().drs_fill_random_f64, np.dtype("float32"): lib().drs_fill_random_f32}[arr.dtype]
+    fn(arr.ctypes.data, arr.size, seed)
+    return arr
+
+
+def check_error(out, ref, halo):
+    """checkError2D/3D (common.hpp:47-102): dict(rms, max_abs, max_idx, max_rel) over the interior."""
+    import numpy as np
+    assert out.shape == ref.shape and out.dtype == ref.dtype
+    nd = out.ndim
+    L, M, N = (out.shape if nd == 3 else (1,) + tuple(out.shape))
+    fn = {np.dtype("float64"): lib().drs_check_error_f64, np.dtype("float32"): lib().drs_check_error_f32}[out.dtype]
+    ma, mi, mr = ctypes.c_double(), ctypes.c_long(), ctypes.c_double()
+    rms = fn(nd, L, M, N, halo, out.ctypes.data, ref.ctypes.data, ma, mi, mr)
+    return dict(rms=rms, max_abs=ma.value, max_idx=mi.value, max_rel=mr.value)

@@ -46,6 +46,28 @@ static std::vector<std::string> to_args(int argc, const char *const *argv) {
     return a;
 }
 
+template <typename T>
+static double check_error(int ndim, int L, int M, int N, int H, const T *out, const T *ref, double *max_abs, long *max_idx, double *max_rel) {
+    const int klo = ndim == 3 ? H : 0, khi = ndim == 3 ? L - H : 1;
+    double err = 0.0, mx = 1e-13, mrel = 0.0;
+    long at = 0;
+    for (int k = klo; k < khi; k++)
+        for (int j = H; j < M - H; j++)
+            for (int i = H; i < N - H; i++) {
+                size_t x = ((size_t)k * M + j) * N + i;
+                double d = std::fabs((double)out[x] - (double)ref[x]);
+                err += d * d;
+                if (d > mx) { mx = d; at = (long)x; }
+                double r = std::fabs((double)ref[x]);
+                double rel = d / (r > 1e-30 ? r : 1e-30);
+                if (rel > mrel) mrel = rel;
+            }
+    if (max_abs) *max_abs = mx;
+    if (max_idx) *max_idx = at;
+    if (max_rel) *max_rel = mrel;
+    return std::sqrt(err / ((double)(khi - klo) * (double)(M - 2 * H) * (double)(N - 2 * H)));
+}
+
 extern "C" {
 
 const char *drs_version(void) { return "drstencil-amd 0.1 (gfx950)"; }
@@ -232,27 +254,6 @@ void drs_fill_random_f32(float *a, size_t n, unsigned seed) {
     for (size_t x = 0; x < n; x++) a[x] = (float)((double)rand() / (double)(RAND_MAX - 1));
 }
 
-template <typename T>
-static double check_error(int ndim, int L, int M, int N, int H, const T *out, const T *ref, double *max_abs, long *max_idx, double *max_rel) {
-    const int klo = ndim == 3 ? H : 0, khi = ndim == 3 ? L - H : 1;
-    double err = 0.0, mx = 1e-13, mrel = 0.0;
-    long at = 0;
-    for (int k = klo; k < khi; k++)
-        for (int j = H; j < M - H; j++)
-            for (int i = H; i < N - H; i++) {
-                size_t x = ((size_t)k * M + j) * N + i;
-                double d = std::fabs((double)out[x] - (double)ref[x]);
-                err += d * d;
-                if (d > mx) { mx = d; at = (long)x; }
-                double r = std::fabs((double)ref[x]);
-                double rel = d / (r > 1e-30 ? r : 1e-30);
-                if (rel > mrel) mrel = rel;
-            }
-    if (max_abs) *max_abs = mx;
-    if (max_idx) *max_idx = at;
-    if (max_rel) *max_rel = mrel;
-    return std::sqrt(err / ((double)(khi - klo) * (double)(M - 2 * H) * (double)(N - 2 * H)));
-}
 double drs_check_error_f64(int ndim, int L, int M, int N, int halo, const double *out, const double *ref, double *max_abs, long *max_idx, double *max_rel) {
     return check_error<double>(ndim, L, M, N, halo, out, ref, max_abs, max_idx, max_rel);
 }

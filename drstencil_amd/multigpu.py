@@ -1,0 +1,185 @@
+"""z-slab decomposition of a 3D stencil run across the GPUs of one node, one process per
+GPU, halo exchange by RCCL send/recv over xGMI (torch.distributed, backend "nccl" == RCCL)
+overlapped with the interior sweep on a second HIP stream.
+
+The reference is single-GPU (no cudaSetDevice / streams / NCCL), so
+this is additive; its semantics are fixed by the single-domain run it must reproduce:
+the global frozen ring stays on the outer faces of rank 0 and rank R-1, every launch
+(src -> dst) is followed by an exchange of dst's H = step*order boundary planes with the
+<= 2 neighbours, and both ping-pong buffers carry H ghost planes per interior face.
+
+Per launch and rank (boundary first, so the exchange overlaps the interior sweep):
+    main stream : boundary kernels (first/last H owned planes)      -> event b
+    comm stream : wait b; batch_isend_irecv of dst's boundary planes -> event c
+    main stream : interior kernel; wait c (next launch reads dst's ghost planes)
+Each neighbour pair talks over its own xGMI link; nothing is all-reduced in the loop.
+
+Kernels are ordinary generated kernels: a z sub-range of a slab is a contiguous view, so
+a "boundary kernel" is the generator's kernel for L = 3H planes and the interior kernel
+the one for the remaining view -- no special device code.
+"""
+import os
+
+import drstencil_amd as drs
+
+
+def slab_bounds(L, world, rank):
+    """Planes [z0, z1) owned by `rank` (balanced split of the outermost dim)."""
+    return (rank * L) // world, ((rank + 1) * L) // world
+
+
+class SlabPlan:
+    """Index bookkeeping for one rank (pure Python; unit-tested on CPU)."""
+
+    def __init__(self, L, H, world, rank):
+        self.L, self.H, self.world, self.rank = L, H, world, rank
+        self.z0, self.z1 = slab_bounds(L, world, rank)
+        self.has_up = rank > 0            # neighbour holding smaller z
+        self.has_dn = rank < world - 1
+        self.lo = self.z0 - (H if self.has_up else 0)   # first global plane held locally
+        self.hi = self.z1 + (H if self.has_dn else 0)
+        self.Lloc = self.hi - self.lo
+        if world > 1 and self.z1 - self.z0 < 2 * H:
+            raise ValueError("slab of %d planes is thinner than 2*halo=%d" % (self.z1 - self.z0, 2 * H))
+        # views (local plane ranges [a,b)) whose kernels write outputs [a+H, b-H)
+        self.top = (0, 3 * H) if self.has_up else None
+        self.bot = (self.Lloc - 3 * H, self.Lloc) if self.has_dn else None
+        a = H if self.has_up else 0
+        b = self.Lloc - (H if self.has_dn else 0)
+        self.interior = (a, b)
+        # planes of dst to send / ghost planes to receive after a launch
+        self.send_up = (H, 2 * H) if self.has_up else None
+        self.recv_up = (0, H) if self.has_up else None
+        self.send_dn = (self.Lloc - 2 * H, self.Lloc - H) if self.has_dn else None
+        self.recv_dn = (self.Lloc - H, self.Lloc) if self.has_dn else None
+
+    def outputs(self):
+        """Global output planes this rank writes per launch (for tests)."""
+        out = []
+        for v in (self.top, self.interior, self.bot):
+            if v is not None and v[1] - v[0] > 2 * self.H:
+                out.append((self.lo + v[0] + self.H, self.lo + v[1] - self.H))
+        return out
+
+
+def _write_view_stc(base_stc, ndim, L_view, cache_dir, tag):
+    """A copy of the spec with L replaced (reference .stc format)."""
+    assert ndim == 3
+    import re
+    text = open(base_stc).read()
+    new_text, n = re.subn(r"(^|\s)L\s+\d+", lambda m: "%sL %d" % (m.group(1), L_view), text, count=1)
+    assert n == 1, "spec has no L"
+    name = os.path.basename(base_stc)[:-4]
+    path = os.path.join(cache_dir, "%s_%s%d.stc" % (name, tag, L_view))
+    tmp = path + ".%d.tmp" % os.getpid()
+    with open(tmp, "w") as f:
+        f.write(new_text)
+    os.replace(tmp, path)
+    return path
+
+
+class HipSweep:
+    """Product sweep backend: generated HIP kernel for a view of Lv planes."""
+
+    def __init__(self, base_stc, opts, cache_dir):
+        self.base_stc, self.opts, self.cache_dir = base_stc, list(opts), cache_dir
+        os.makedirs(cache_dir, exist_ok=True)
+        self.kernels = {}
+
+    def kernel(self, Lv):
+        if Lv not in self.kernels:
+            stc = _write_view_stc(self.base_stc, 3, Lv, self.cache_dir, "slabL")
+            self.kernels[Lv] = drs.Kernel(self.opts + [stc])
+        return self.kernels[Lv]
+
+    def __call__(self, src_view, dst_view, stream):
+        k = self.kernel(src_view.shape[0])
+        k.launch(src_view.data_ptr(), dst_view.data_ptr(), stream)
+
+
+class SlabRun:
+    """One rank of a z-slab decomposed run.
+
+    sweep(src_view, dst_view, stream_handle) must apply one launch of the (fused) stencil
+    to a contiguous [Lv, M, N] view: outputs planes [H, Lv-H) of dst_view (HipSweep in the
+    product; the CPU tests inject an oracle-backed callable to check the decomposition)."""
+
+    def __init__(self, torch, dist, L, M, N, H, step, iterations, rank, world, sweep, device, dtype):
+        self.torch, self.dist = torch, dist
+        self.plan = SlabPlan(L, H, world, rank)
+        self.M, self.N, self.H, self.step, self.iterations = M, N, H, step, iterations
+        self.rank, self.world, self.sweep = rank, world, sweep
+        self.device, self.dtype = device, dtype
+        self.gpu = (device.type == "cuda")
+        p = self.plan
+        self.A = torch.zeros((p.Lloc, M, N), dtype=dtype, device=device)
+        self.B = torch.zeros((p.Lloc, M, N), dtype=dtype, device=device)
+        if self.gpu:
+            self.main = torch.cuda.current_stream(device)
+            self.comm = torch.cuda.Stream(device=device)
+            self.ev_b = torch.cuda.Event()
+            self.ev_c = torch.cuda.Event()
+        self.launch_count = 0
+
+    def load_global(self, fill):
+        """fill(lo, hi) -> tensor/array of global planes [lo, hi) for buffer A (B starts as zeros)."""
+        p = self.plan
+        self.A.copy_(self.torch.as_tensor(fill(p.lo, p.hi)).to(self.device, self.dtype))
+        self.B.zero_()
+
+    def _stream_handle(self):
+        return self.main.cuda_stream if self.gpu else 0
+
+    def _exchange(self, dst):
+        p, dist = self.plan, self.dist
+        ops = []
+        if p.has_up:
+            ops.append(dist.P2POp(dist.isend, dst[p.send_up[0]:p.send_up[1]], self.rank - 1))
+            ops.append(dist.P2POp(dist.irecv, dst[p.recv_up[0]:p.recv_up[1]], self.rank - 1))
+        if p.has_dn:
+            ops.append(dist.P2POp(dist.isend, dst[p.send_dn[0]:p.send_dn[1]], self.rank + 1))
+            ops.append(dist.P2POp(dist.irecv, dst[p.recv_dn[0]:p.recv_dn[1]], self.rank + 1))
+        if not ops:
+            return
+        for w in dist.batch_isend_irecv(ops):
+            w.wait()
+
+    def launch(self, src, dst):
+        """One launch src -> dst with halo exchange of dst (boundary first)."""
+        p, H = self.plan, self.H
+        sh = self._stream_handle()
+        for v in (p.top, p.bot):
+            if v is not None:
+                self.sweep(src[v[0]:v[1]], dst[v[0]:v[1]], sh)
+        if self.world > 1:
+            if self.gpu:
+                self.ev_b.record(self.main)
+                with self.torch.cuda.stream(self.comm):
+                    self.comm.wait_event(self.ev_b)
+                    self._exchange(dst)
+                    self.ev_c.record(self.comm)
+        a, b = p.interior
+        if b - a > 2 * H:
+            self.sweep(src[a:b], dst[a:b], sh)
+        if self.world > 1:
+            if self.gpu:
+                self.main.wait_event(self.ev_c)
+            else:
+                self._exchange(dst)
+        self.launch_count += 1
+
+    def run(self, iterations=None):
+        """The reference's ping-pong loop (codegen.hpp:581-584) on the slab; result in A."""
+        it = self.iterations if iterations is None else iterations
+        n, t = 0, 0
+        while t < it:
+            self.launch(self.A, self.B)
+            self.launch(self.B, self.A)
+            n += 2
+            t += 2 * self.step
+        return n
+
+    def owned(self, buf):
+        """The planes of `buf` this rank owns (global [z0, z1))."""
+        p = self.plan
+        return buf[p.z0 - p.lo:p.z1 - p.lo]

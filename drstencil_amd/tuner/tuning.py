@@ -1,0 +1,262 @@
+#!/usr/bin/env python3
+"""tuning.py -- tuning-space enumerator and search driver for the MI355X generator.
+
+Counterpart of the reference's per-stencil benchmarks/<stencil>/tuning.py
+(FilterParams 13-37, cfgToCommandLine 40-58, cfgToString 61-78, getMetrics 84-100,
+searchSpace 102-142 in benchmarks/3d7pt_star/tuning.py; the 2D variant in
+benchmarks/2d5pt_star/tuning.py:13-164).  Same structure -- filter -> shuffled exhaustive
+sweep -> per-config generate/compile/measure -> append every improvement to duration.log
+-- but the space is HIP/CDNA4 shaped and the objective comes from HIP events and
+rocprofv3 instead of Nsight Compute:
+
+  space vector = (step, dist, (bx, by), sn, unroll, blockMergeX, mx, blockMergeY, my,
+                  mergeForward, prefetch, xrim, lazy)
+  * bx in {16,32,64,128,256}: lanes along x; mx in {1,2,4} points per lane (16-byte
+    accesses at mx=4 fp32 / 2 fp64); by*my rows per tile; sn planes per stream block
+  * LDS budget 160 KiB per CU (the reference caps at 32 KiB of A100 shared memory)
+  * `duration` = average kernel duration in ns from HIP events over the reference's timed
+    loop (10 warm-up launches first, codegen.hpp:575-584), i.e. what `ncu ... Duration` was
+    for the reference; `rocprof_metrics()` adds FETCH_SIZE/WRITE_SIZE for chosen configs.
+
+The config-name scheme (`fu2d1bx16y8sn8u4cmx1cmy1mf5[p]`) and the command-line mapping are
+the reference's, with suffixes for the additive options, so logs stay comparable.
+"""
+import argparse
+import datetime
+import itertools
+import json
+import os
+import random
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+maxThreadsPerBlockLg2 = 10   # 1024 lanes per workgroup
+maxLdsPerBlock = 160 * 1024  # bytes of LDS a single workgroup may use on gfx950
+order = 1                    # stencil order (set per stencil by main())
+ndim = 3
+elem_bytes = 4
+
+
+def FilterParams(spaceVector):
+    step, dist, blockSize, sn, s_unroll, blockMergeX, mergeFactorX, blockMergeY, mergeFactorY, m_threshold, prefetch, xrim, lazy = spaceVector
+    halo = step * order
+    tx = mergeFactorX * blockSize[0]
+    ty = mergeFactorY * blockSize[1] if ndim == 3 or blockSize[1] > 0 else 1
+    # LDS: (slots) x (rows + halo pads) x (row + x halo) -- an upper bound with 3 slots
+    ldsUsage = 3 * (ty + 2 * halo) * (tx + 8) * elem_bytes
+    if ldsUsage > maxLdsPerBlock:
+        return False
+    # dist too big or too small (reference rule; dist > halo is wrong in the reference)
+    if dist > step * order or dist < (step - 1) * order:
+        return False
+    # the tile must keep rows after removing the y halo, and x halo must fit the tile
+    if ty - 2 * halo < 1 or tx < 2 * halo:
+        return False
+    # a wavefront is 64 lanes: partial waves waste lanes
+    if (blockSize[0] * max(blockSize[1], 1)) % 64 != 0:
+        return False
+    # one row segment per wavefront instruction wants >= 128 contiguous bytes
+    if tx * elem_bytes < 128:
+        return False
+    # duplicates: block merging with factor 1 == cyclic merging with factor 1
+    if blockMergeX and mergeFactorX == 1:
+        return False
+    if blockMergeY and mergeFactorY == 1:
+        return False
+    # cyclic x lays points out like block x on CDNA4 (plan.hpp): keep one of them
+    if not blockMergeX and mergeFactorX > 1:
+        return False
+    return True
+
+
+def cfgToCommandLine(spaceVector):
+    step, dist, blockSize, sn, s_unroll, blockMergeX, mergeFactorX, blockMergeY, mergeFactorY, m_threshold, prefetch, xrim, lazy = spaceVector
+    cmd = " --bx {0} --by {1} --sn {2} --stream-unroll {3}".format(blockSize[0], blockSize[1], sn, s_unroll)
+    cmd += " --step {0} --dist {1}".format(step, dist)
+    if blockMergeX:
+        cmd += " --block-merge-x {0}".format(mergeFactorX)
+    else:
+        cmd += " --cyclic-merge-x {0}".format(mergeFactorX)
+    if blockMergeY:
+        cmd += " --block-merge-y {0}".format(mergeFactorY)
+    else:
+        cmd += " --cyclic-merge-y {0}".format(mergeFactorY)
+    cmd += " --merge-forward {0}".format(m_threshold)
+    if prefetch:
+        cmd += " --prefetch"
+    cmd += " --xrim {0} --lazy-rims {1}".format(xrim, lazy)
+    return cmd
+
+
+def cfgToString(spaceVector):
+    step, dist, blockSize, sn, s_unroll, blockMergeX, mergeFactorX, blockMergeY, mergeFactorY, m_threshold, prefetch, xrim, lazy = spaceVector
+    cmd = "fu{0}d{1}bx{2}y{3}sn{4}u{5}".format(step, dist, blockSize[0], blockSize[1], sn, s_unroll)
+    cmd += ("bmx{0}" if blockMergeX else "cmx{0}").format(mergeFactorX)
+    cmd += ("bmy{0}" if blockMergeY else "cmy{0}").format(mergeFactorY)
+    cmd += "mf{0}".format(m_threshold)
+    if prefetch:
+        cmd += "p"
+    cmd += "x" + xrim[0] + ("z" if lazy else "e")
+    return cmd
+
+
+def enumerate_space(steps=(1,), full=False):
+    if ndim == 3:
+        blockSizes = [(bx, by) for bx in (16, 32, 64, 128, 256) for by in (1, 2, 4, 8, 16) if bx * by <= 2 ** maxThreadsPerBlockLg2]
+        sns = [16, 32, 64, 128] if not full else [8, 16, 32, 64, 128, 256]
+        mys = [1, 2, 4, 8]
+    else:
+        blockSizes = [(bx, by) for bx in (64, 128, 256) for by in (1, 2, 4, 8) if bx * by <= 2 ** maxThreadsPerBlockLg2]
+        sns = [32, 64, 128, 256]
+        mys = [1, 2, 4, 8, 16]
+    vec = 16 // elem_bytes
+    space = itertools.product(
+        list(steps),
+        [0],                       # dist: filled per step below
+        blockSizes, sns,
+        [4, 8] if full else [4],   # stream unroll
+        [True], [vec] if not full else [vec // 2, vec],
+        [False, True], mys,
+        [5],
+        [False, True],
+        ["lds", "dpp"],
+        [1, 0],
+    )
+    out = []
+    for v in space:
+        v = list(v)
+        v[1] = v[0] * order
+        v = tuple(v)
+        if FilterParams(v):
+            out.append(v)
+    return out
+
+
+def getElapsedTime(start, end):
+    return (end - start).seconds + (end - start).microseconds / 1e6
+
+
+def measure(kern, torch, A, B, iterations, warmup=10):
+    """HIP-event duration of one launch in ns, reference protocol (10 warm-ups, timed loop)."""
+    n, ms = kern.run_timed(A.data_ptr(), B.data_ptr(), iterations=iterations, warmup=warmup, stream=torch.cuda.current_stream().cuda_stream)
+    return ms * 1e6 / max(n, 1)
+
+
+def _build(job):
+    import drstencil_amd as drs
+    name, args = job
+    try:
+        k = drs.Kernel(args)
+        return name, True, k.path
+    except Exception as e:
+        return name, False, str(e)[-400:]
+
+
+def searchSpace(stc, is3d, dtype, configs, outdir, iterations=8, budget_s=None, jobs=8, extra_opts=()):
+    """Sweep `configs` (space vectors or raw option strings).
+
+    Phase 1 generates + compiles every configuration (hipcc, parallel) BEFORE this process
+    touches the GPU -- a process that has initialised HIP must not fork/exec compilers.
+    Phase 2 loads and times them.  Improvements go to duration.log (seconds-since-start,
+    best ns, name), every result to results.jsonl."""
+    from concurrent.futures import ProcessPoolExecutor
+    os.makedirs(outdir, exist_ok=True)
+    startTime = datetime.datetime.now()
+    named = []
+    for c in configs:
+        if isinstance(c, str):
+            named.append((c.strip().replace(" ", "").replace("--", "_"), c.split()))
+        else:
+            named.append((cfgToString(c), cfgToCommandLine(c).split()))
+    base = (["--3d"] if is3d else []) + ["--dtype", dtype] + list(extra_opts)
+    jobsl = [(n, base + a + [stc]) for n, a in named]
+    built = []
+    t_start = time.time()
+    with ProcessPoolExecutor(max_workers=jobs) as ex:
+        for cnt, (name, ok, info) in enumerate(ex.map(_build, jobsl), 1):
+            if ok:
+                built.append(name)
+            else:
+                print("{0}/{1}: {2} BUILD FAILED {3}".format(cnt, len(jobsl), name, info.splitlines()[-1] if info else ""), flush=True)
+    print("built {0}/{1} configurations in {2:.0f} s".format(len(built), len(jobsl), time.time() - t_start), flush=True)
+
+    import torch
+    import drstencil_amd as drs
+    argmap = dict(jobsl)
+    best = 1e18
+    results = []
+    spec = drs.Spec(stc, 3 if is3d else 2, 1)
+    L, M, N = spec.dims
+    shape = (L, M, N) if is3d else (M, N)
+    tdt = torch.float32 if dtype == "fp32" else torch.float64
+    kerns = [(n, drs.Kernel(argmap[n])) for n in built]      # cache hits: no compiler runs
+    A = torch.rand(shape, dtype=tdt, device="cuda")
+    B = torch.zeros_like(A)
+    esz = 4 if dtype == "fp32" else 8
+    npts = A.numel()
+    t_start = time.time()
+    for cnt, (name, kern) in enumerate(kerns, 1):
+        dur = measure(kern, torch, A, B, iterations)
+        gbs = 2.0 * esz * npts / dur
+        gst = kern.updates_per_launch() / dur
+        rec = dict(name=name, args=" ".join(argmap[name][:-1]), duration_ns=dur, GBps=gbs, frac=gbs / 8000.0, GStencil=gst,
+                   lds=kern.info["lds_bytes"], threads=kern.info["threads"], step=kern.info["step"])
+        results.append(rec)
+        with open(os.path.join(outdir, "results.jsonl"), "a") as f:
+            f.write(json.dumps(rec) + "\n")
+        print("{0}/{1}: {2}  {3:.0f} ns  {4:.0f} GB/s ({5:.1f}%)  {6:.1f} GStencil/s".format(
+            cnt, len(kerns), name, dur, gbs, gbs / 80.0, gst), flush=True)
+        if dur < best:
+            best = dur
+            with open(os.path.join(outdir, "duration.log"), "a") as f:
+                f.write(str((datetime.datetime.now() - startTime).seconds) + " s, " + str(int(best)) + ", " + name + "\n")
+        if budget_s and time.time() - t_start > budget_s:
+            print("time budget reached", flush=True)
+            break
+    with open(os.path.join(outdir, "duration.log"), "a") as f:
+        f.write(str((datetime.datetime.now() - startTime).seconds) + " s, " + str(int(best)) + "\n")
+    results.sort(key=lambda r: r["duration_ns"])
+    return results
+
+
+def main():
+    global order, ndim, elem_bytes
+    ap = argparse.ArgumentParser(description="tuning-space search for one stencil on the local MI355X")
+    ap.add_argument("stc")
+    ap.add_argument("--3d", dest="is3d", action="store_true")
+    ap.add_argument("--dtype", default="fp32")
+    ap.add_argument("--order", type=int, default=1)
+    ap.add_argument("--steps", default="1")
+    ap.add_argument("--max-configs", type=int, default=0, help="random subset size (0 = all)")
+    ap.add_argument("--budget", type=float, default=0, help="wall-clock budget in seconds (reference 2D: 3600)")
+    ap.add_argument("--out", default="tuning_out")
+    ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--list", action="store_true", help="only print the space size and the first configs")
+    ap.add_argument("--configs-file", default=None, help="file with one raw option string per line instead of the space")
+    a = ap.parse_args()
+    order, ndim, elem_bytes = a.order, (3 if a.is3d else 2), (4 if a.dtype == "fp32" else 8)
+    if a.configs_file:
+        paras = [l.strip() for l in open(a.configs_file) if l.strip() and not l.startswith("#")]
+    else:
+        paras = enumerate_space(tuple(int(s) for s in a.steps.split(",")))
+        random.seed(a.seed)
+        random.shuffle(paras)
+        if a.max_configs:
+            paras = paras[:a.max_configs]
+    if a.list:
+        print(len(paras), "configurations")
+        for p in paras[:5]:
+            print(cfgToString(p) if not isinstance(p, str) else p, "|", cfgToCommandLine(p) if not isinstance(p, str) else "")
+        return
+    res = searchSpace(os.path.abspath(a.stc), a.is3d, a.dtype, paras, a.out, budget_s=a.budget or None)
+    print("best:")
+    for r in res[:10]:
+        print("  {name}  {duration_ns:.0f} ns  {GBps:.0f} GB/s  {GStencil:.1f} GStencil/s".format(**r))
+
+
+if __name__ == "__main__":
+    main()

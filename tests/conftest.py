@@ -19,3 +19,26 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN
+
+
+def pytest_sessionstart(session):
+    """GPU sessions: make sure every kernel the gpu tests use is built (normally a cache hit:
+    __graft_entry__.build() prebuilds them) BEFORE anything initialises HIP -- a process that
+    has touched the GPU must not fork/exec hipcc."""
+    markexpr = session.config.getoption("-m") or ""
+    if "gpu" not in markexpr or "not gpu" in markexpr:
+        return
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import drstencil_amd as drs
+    from gpu_cases import all_build_args, golden_args
+    from helpers import golden_cases, load_golden
+    jobs = all_build_args()
+    for c in golden_cases():
+        meta, *_ = load_golden(c)
+        opts, stc = golden_args(c, meta)
+        jobs.append(opts + [stc])
+    from gpu_cases import stc as stcp
+    jobs.append(["--dtype", "fp32", "--streaming", "--xrim", "lds", stcp("t2_box25")])
+    jobs.append(["--dtype", "fp32", "--streaming", "--xrim", "dpp", stcp("t2_box25")])
+    for j in jobs:
+        drs.Kernel(j)

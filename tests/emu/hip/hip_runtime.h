@@ -38,10 +38,12 @@ using std::min;
 namespace emu {
 struct Fiber {
     ucontext_t ctx;
-    std::vector<char> stack;
+    char *stack = nullptr;
     bool done = false;
     emu_uint3 tid;
 };
+constexpr size_t kStack = 128 * 1024;
+inline std::vector<char *> stack_pool;   // reused across workgroups (no zero fill)
 inline ucontext_t sched_ctx;
 inline Fiber *cur = nullptr;
 inline std::function<void()> *body = nullptr;
@@ -56,15 +58,17 @@ inline void yield() { swapcontext(&cur->ctx, &sched_ctx); }
 
 inline void run_block(dim3 block, std::function<void()> fn) {
     const unsigned nt = block.x * block.y * block.z;
-    std::vector<Fiber> fibers(nt);
+    static std::vector<Fiber> fibers;
+    fibers.assign(nt, Fiber());
+    while (stack_pool.size() < nt) stack_pool.push_back((char *)malloc(kStack));
     body = &fn;
     for (unsigned t = 0; t < nt; t++) {
         Fiber &f = fibers[t];
-        f.stack.resize(256 * 1024);
+        f.stack = stack_pool[t];
         f.tid.x = t % block.x; f.tid.y = (t / block.x) % block.y; f.tid.z = t / (block.x * block.y);
         getcontext(&f.ctx);
-        f.ctx.uc_stack.ss_sp = f.stack.data();
-        f.ctx.uc_stack.ss_size = f.stack.size();
+        f.ctx.uc_stack.ss_sp = f.stack;
+        f.ctx.uc_stack.ss_size = kStack;
         f.ctx.uc_link = &sched_ctx;
         makecontext(&f.ctx, (void (*)())trampoline, 0);
     }

@@ -1,0 +1,74 @@
+"""Kernel configurations exercised on the GPU (tests -m gpu) and prebuilt by
+__graft_entry__.build() so that the GPU box finds them in drstencil_amd/_kcache."""
+import os
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+STC = os.path.join(ROOT, "tests", "stc")
+CFG = os.path.join(ROOT, "benchmarks", "configs")
+
+
+def stc(name):
+    return os.path.join(STC, name + ".stc")
+
+
+# (id, ndim, stc, options)
+SMALL = []
+
+
+def _add(cid, ndim, name, *opts):
+    SMALL.append((cid, ndim, stc(name), (["--3d"] if ndim == 3 else []) + list(opts)))
+
+
+for dt in ("fp32", "fp64"):
+    _add("3d7_%s_default" % dt, 3, "t3_star", "--dtype", dt)
+    _add("3d7_%s_prefetch_dpp" % dt, 3, "t3_star", "--dtype", dt, "--prefetch", "--xrim", "dpp", "--sn", "16")
+    _add("3d7_%s_step2" % dt, 3, "t3_star", "--dtype", dt, "--step", "2", "--sn", "32")
+    _add("2d5_%s_tile" % dt, 2, "t2_star", "--dtype", dt)
+    _add("2d5_%s_stream" % dt, 2, "t2_star", "--dtype", dt, "--streaming", "--sn", "40")
+    _add("2d25_%s_tile" % dt, 2, "t2_box25", "--dtype", dt)
+    _add("2d25_%s_stream_dpp" % dt, 2, "t2_box25", "--dtype", dt, "--streaming", "--xrim", "dpp", "--prefetch")
+_add("3d7_fp32_step3", 3, "t3_star", "--dtype", "fp32", "--step", "3", "--sn", "16")
+_add("3d7_fp32_eager", 3, "t3_star", "--dtype", "fp32", "--lazy-rims", "0", "--prefetch")
+_add("3d7_fp32_cyclicy", 3, "t3_star", "--dtype", "fp32", "--cyclic-merge-y", "3", "--by", "2", "--bx", "32", "--sn", "9")
+_add("3d7_fp32_bx128", 3, "t3_star", "--dtype", "fp32", "--bx", "128", "--by", "2", "--block-merge-y", "2", "--xrim", "dpp")
+_add("3d7_fp32_refdefaults", 3, "t3_star", "--dtype", "fp32", "--ref-defaults")
+_add("3d7_fp32_nt", 3, "t3_star", "--dtype", "fp32", "--nt-store", "1", "--nt-load", "1", "--xcd-remap", "0")
+_add("3d7_fp32_oddN", 3, "t3_star_odd", "--dtype", "fp32")
+_add("3d7_fp64_oddN_dpp", 3, "t3_star_odd", "--dtype", "fp64", "--xrim", "dpp", "--block-merge-x", "2", "--bx", "16", "--by", "4")
+_add("3d9x_fp32", 3, "t3_cross", "--dtype", "fp32", "--dist", "2")
+_add("3d9x_fp64_step2_dpp", 3, "t3_cross", "--dtype", "fp64", "--dist", "2", "--step", "2", "--xrim", "dpp")
+_add("3dodd_fp32", 3, "t3_odd", "--dtype", "fp32")
+_add("3dodd_fp64_step2", 3, "t3_odd", "--dtype", "fp64", "--step", "2")
+_add("2d5x_fp32", 2, "t2_cross", "--dtype", "fp32", "--dist", "2")
+_add("2d5x_fp64_stream", 2, "t2_cross", "--dtype", "fp64", "--dist", "2", "--streaming")
+_add("2d9b_fp32", 2, "t2_box9", "--dtype", "fp32", "--xrim", "dpp")
+_add("2d9s_fp32_stream", 2, "t2_star9", "--dtype", "fp32", "--streaming", "--prefetch")
+_add("2d9x_fp64", 2, "t2_cross9", "--dtype", "fp64", "--dist", "2")
+_add("2d5_fp32_step2_stream", 2, "t2_star", "--dtype", "fp32", "--step", "2", "--streaming", "--xrim", "dpp")
+_add("2d25_fp64_step2", 2, "t2_box25", "--dtype", "fp64", "--step", "2")
+_add("2dodd_fp32_it5", 2, "t2_odd", "--dtype", "fp32")
+_add("2dodd_fp64_step2_stream", 2, "t2_odd", "--dtype", "fp64", "--step", "2", "--streaming")
+
+SMOKE = ("smoke3", 3, stc("smoke3"), ["--3d", "--dtype", "fp32"])
+
+# BASELINE.json configs at full size: (id, ndim, stc, options)
+FULL = [
+    ("C2_2d5pt_8192_fp32_tile", 2, os.path.join(CFG, "c2_2d5pt_star_8192.stc"), ["--dtype", "fp32"]),
+    ("C2_2d5pt_8192_fp32_stream", 2, os.path.join(CFG, "c2_2d5pt_star_8192.stc"), ["--dtype", "fp32", "--streaming"]),
+    ("C3_3d7pt_512_fp32", 3, os.path.join(CFG, "c3_3d7pt_star_512.stc"), ["--3d", "--dtype", "fp32"]),
+    ("C3_3d7pt_512_fp32_step2", 3, os.path.join(CFG, "c3_3d7pt_star_512.stc"), ["--3d", "--dtype", "fp32", "--step", "2"]),
+    ("C4_3d7pt_1024_fp32", 3, os.path.join(CFG, "c4_3d7pt_star_1024.stc"), ["--3d", "--dtype", "fp32"]),
+    ("C5_2d25pt_16384_fp64", 2, os.path.join(CFG, "c5_2d25pt_box_16384.stc"), ["--dtype", "fp64"]),
+]
+
+
+def all_build_args():
+    out = [c[3] + [c[2]] for c in SMALL] + [SMOKE[3] + [SMOKE[2]]] + [c[3] + [c[2]] for c in FULL]
+    return out
+
+
+def golden_args(case, meta):
+    """Options for running a golden fixture case through the HIP path (fp64, like the reference)."""
+    opts = (["--3d"] if meta["ndim"] == 3 else []) + ["--dtype", "fp64", "--step", str(meta["step"]), "--dist", str(meta["macros"]["Dist"]),
+                                                       "--bx", "16", "--by", "4", "--block-merge-x", "2", "--block-merge-y", "4", "--sn", "4"]
+    return opts, stc("gold_" + case)

@@ -1,0 +1,82 @@
+"""Emitted HIP kernels executed on the CPU (fiber emulation of workgroups, tests/emu) --
+checks the generator's index math, guards, halo loaders, LDS exchange, register rotation,
+DPP path and prefetch pipeline without a GPU.  The GPU run of the same kernels is in
+test_gpu_parity.py."""
+import os
+
+import numpy as np
+import pytest
+
+import oracle
+from emu_util import build_emulated, run_emulated
+from gpu_cases import golden_args
+from helpers import golden_cases, load_golden, write_stc
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.parametrize("case", golden_cases())
+def test_emulated_kernel_vs_reference_golden(case, tmp_path):
+    meta, a0, a_ref, b_ref = load_golden(case)
+    opts, stc = golden_args(case, meta)
+    lib = build_emulated(tmp_path, stc, opts)
+    A = np.ascontiguousarray(a0.copy()); B = np.zeros_like(A)
+    n = run_emulated(lib, A, B, meta["iterations"], meta["step"])
+    assert n == meta["launches"]
+    spec = oracle.Spec(stc, meta["ndim"], meta["step"])
+    # fixtures are uncontracted fp64, the kernel is an FMA chain
+    assert oracle.check(spec, A, a_ref)["max_rel"] < 1e-12
+    assert oracle.check(spec, B, b_ref)["max_rel"] < 1e-12
+    h = spec.halo
+    ring = np.ones(A.shape, bool)
+    ring[tuple(slice(h, s - h) for s in A.shape)] = False
+    assert np.array_equal(A[ring], a_ref[ring]) and np.array_equal(B[ring], b_ref[ring])
+    # and bit-exact against the oracle's contracted mode
+    A2 = a0.copy(); B2 = np.zeros_like(A2)
+    oracle.run(spec, A2, B2, contract=1)
+    assert np.array_equal(A, A2) and np.array_equal(B, B2)
+
+
+def _mg():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("mg", os.path.join(ROOT, "oracle", "make_golden.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    return m
+
+
+VARIANTS = [
+    ("3d_default_fp32", 3, "STAR3", (19, 23, 520), ["--3d", "--dtype", "fp32", "--sn", "8"]),
+    ("3d_prefetch_dpp_eager", 3, "STAR3", (19, 23, 520), ["--3d", "--dtype", "fp32", "--sn", "7", "--prefetch", "--xrim", "dpp", "--lazy-rims", "0"]),
+    ("3d_cyclicy_fp64", 3, "STAR3", (15, 29, 140), ["--3d", "--dtype", "fp64", "--sn", "5", "--cyclic-merge-y", "3", "--by", "2", "--bx", "32"]),
+    ("3d_step2_dpp_prefetch", 3, "STAR3", (17, 21, 300), ["--3d", "--dtype", "fp32", "--sn", "6", "--step", "2", "--prefetch", "--xrim", "dpp"]),
+    ("3d_oddN_scalar", 3, "STAR3", (12, 17, 263), ["--3d", "--dtype", "fp32", "--sn", "8"]),
+    ("3d_bx128_dpp", 3, "STAR3", (12, 19, 1030), ["--3d", "--dtype", "fp32", "--bx", "128", "--by", "2", "--block-merge-y", "2", "--xrim", "dpp"]),
+    ("3d_cross_step2", 3, "CROSS3", (14, 19, 136), ["--3d", "--dtype", "fp64", "--dist", "2", "--step", "2", "--xrim", "dpp"]),
+    ("2d_tile_fp32", 2, "STAR2", (1, 75, 530), ["--dtype", "fp32"]),
+    ("2d_stream_step3_dpp", 2, "STAR2", (1, 75, 530), ["--dtype", "fp64", "--streaming", "--prefetch", "--xrim", "dpp", "--sn", "16", "--step", "3"]),
+    ("2d25_tile_fp64", 2, "BOX25", (1, 61, 268), ["--dtype", "fp64"]),
+    ("2d25_stream_step2", 2, "BOX25", (1, 61, 268), ["--dtype", "fp32", "--streaming", "--sn", "9", "--step", "2", "--prefetch"]),
+    ("2d_refdefaults", 2, "BOX9", (1, 41, 70), ["--dtype", "fp64", "--ref-defaults"]),
+]
+
+
+@pytest.mark.parametrize("vid,ndim,pts,dims,opts", VARIANTS, ids=[v[0] for v in VARIANTS])
+def test_emulated_variants_bit_exact(vid, ndim, pts, dims, opts, tmp_path):
+    mg = _mg()
+    stc = str(tmp_path / "v.stc")
+    write_stc(stc, ndim, dims, 4, getattr(mg, pts))
+    step = int(opts[opts.index("--step") + 1]) if "--step" in opts else 1
+    lib = build_emulated(tmp_path, stc, opts)
+    spec = oracle.Spec(stc, ndim, step)
+    dt = np.float32 if "fp32" in opts else np.float64
+    A = oracle.fill_random(spec.shape, dt); B = np.zeros_like(A)
+    A2, B2 = A.copy(), B.copy()
+    oracle.run(spec, A2, B2, contract=1)
+    n = run_emulated(lib, A, B, spec.iterations, step)
+    assert n == spec.launches
+    assert np.array_equal(A, A2) and np.array_equal(B, B2)
+    # the emitted gold kernel too
+    A3 = oracle.fill_random(spec.shape, dt); B3 = np.zeros_like(A3)
+    run_emulated(lib, A3, B3, spec.iterations, step, gold=True)
+    assert np.array_equal(A3, A2) and np.array_equal(B3, B2)
