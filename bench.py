@@ -33,10 +33,10 @@ WORKLOADS = {
 }
 # tuned generator options per workload (see profiles/ and DESIGN.md; found with drstencil_amd/tuner)
 TUNED = {
-    "c4": ["--3d", "--dtype", "fp32"],
-    "c3": ["--3d", "--dtype", "fp32"],
-    "c2": ["--dtype", "fp32", "--streaming"],
-    "c5": ["--dtype", "fp64", "--streaming"],
+    "c4": ["--3d", "--dtype", "fp32", "--bx", "64", "--by", "4", "--block-merge-x", "4", "--block-merge-y", "8", "--sn", "8", "--xcd-remap", "2"],
+    "c3": ["--3d", "--dtype", "fp32", "--bx", "64", "--by", "4", "--block-merge-x", "4", "--block-merge-y", "8", "--sn", "8", "--xcd-remap", "1"],
+    "c2": ["--dtype", "fp32", "--bx", "64", "--by", "4", "--block-merge-x", "4", "--block-merge-y", "8", "--xcd-remap", "0"],
+    "c5": ["--dtype", "fp64", "--bx", "64", "--by", "4", "--block-merge-x", "2", "--block-merge-y", "8", "--xcd-remap", "0"],
 }
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak (MI355X_MICROARCH.md: 8.0 TB/s spec)
 

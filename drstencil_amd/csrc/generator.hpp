@@ -73,10 +73,15 @@ Options:
 MI355X options:
 
 --dtype <fp32|fp64>     Element type (fp64 by default, as the reference).
---xrim <lds|dpp>        x halo inside a wavefront through LDS or by DPP wave shifts.
+--xrim <lds|dpp>        x halo inside a wavefront by DPP wave shifts (default) or through LDS.
+--schedule <scatter|window>  scatter (default): every arriving plane adds its taps to the
+                        partial sums of the output planes in flight (carried in VGPRs);
+                        window: keep a rotating register window per resident plane.
 --lazy-rims <0|1>       Read LDS rims when first needed (1) or when a plane arrives (0).
---xcd-remap <0|1>       XCD-aware workgroup to tile mapping (1 by default).
---nt-store <0|1>        Non-temporal stores of the output.
+--xcd-remap <0|1|2>     workgroup to tile mapping: 0 dispatch order, 1 contiguous chunk of tiles
+                        per XCD, 2 one x-y band per XCD with all XCDs on the same stream block
+                        (default: 2 for 3D, 0 for 2D).
+--nt-store <0|1>        Non-temporal stores of the output (1 by default).
 --nt-load <0|1>         Non-temporal loads of the input.
 --waves-per-eu <num>    Second argument of __launch_bounds__.
 --lds-pad <num>         Extra elements of padding per LDS row.
@@ -125,6 +130,7 @@ inline GenResult generate(const std::vector<std::string> &args /* argv[1..] */) 
         // ---- additive options
         else if (a == "--dtype") { if (!str_opt(o.dtype)) break; }
         else if (a == "--xrim") { if (!str_opt(o.xrim)) break; }
+        else if (a == "--schedule") { if (!str_opt(o.schedule)) break; }
         else if (a == "--lazy-rims") { if (!int_opt(o.lazy_rims, nullptr)) break; }
         else if (a == "--xcd-remap") { if (!int_opt(o.xcd_remap, nullptr)) break; }
         else if (a == "--nt-store") { if (!int_opt(o.nt_store, nullptr)) break; }
@@ -136,6 +142,7 @@ inline GenResult generate(const std::vector<std::string> &args /* argv[1..] */) 
     }
     if (illegal_exit) return res;
     if (o.dtype != "fp32" && o.dtype != "fp64") { res.messages += "Illegal input.\n"; res.exit_code = 255; return res; }
+    if (o.schedule != "scatter" && o.schedule != "window") { res.messages += "Illegal input.\n"; res.exit_code = 255; return res; }
     if (o.xrim != "lds" && o.xrim != "dpp") { res.messages += "Illegal input.\n"; res.exit_code = 255; return res; }
     if (o.step < 1) { res.messages += "Illegal input.\n"; res.exit_code = 255; return res; }
 

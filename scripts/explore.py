@@ -1,0 +1,114 @@
+#!/usr/bin/env python3
+"""Exploration harness (GPU box): times generated kernels for ad-hoc (dims, options) pairs
+and a device-to-device copy as the practical HBM ceiling.  Builds everything before HIP is
+initialised.  Usage: explore.py <experiment-file> <outdir>; experiment lines:
+    <name> | <ndim> | <L> <M> <N> | <stencil: star3|star2|box25> | <dtype> | <options...>"""
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import drstencil_amd as drs
+from helpers import write_stc
+
+STAR3 = [(0, 0, 0, 0.3), (1, 0, 0, 0.2), (-1, 0, 0, 0.2), (0, 1, 0, 0.2), (0, -1, 0, 0.2), (0, 0, 1, 0.2), (0, 0, -1, 0.2)]
+STAR2 = [(0, 0, 0.3), (0, 1, 0.2), (1, 0, 0.2), (0, -1, 0.2), (-1, 0, 0.2)]
+BOX25 = [(0, 0, 0.3), (1, 0, 0.2), (0, 1, 0.2), (-1, 0, 0.2), (0, -1, 0.2), (1, 1, 0.1), (1, -1, 0.1), (-1, 1, 0.1), (-1, -1, 0.1),
+         (2, 0, 0.1), (0, 2, 0.1), (-2, 0, 0.1), (0, -2, 0.1), (1, 2, 0.05), (-1, 2, 0.05), (1, -2, 0.05), (-1, -2, 0.05),
+         (-2, 1, 0.05), (2, -1, 0.05), (-2, -1, 0.05), (2, 1, 0.05), (2, 2, 0.02), (2, -2, 0.02), (-2, 2, 0.02), (-2, -2, 0.02)]
+PTS = dict(star3=STAR3, star2=STAR2, box25=BOX25)
+
+
+def _build(job):
+    try:
+        k = drs.Kernel(job)
+        return True, k.path
+    except Exception as e:
+        return False, str(e)[-300:]
+
+
+def main():
+    exp, outdir = sys.argv[1], sys.argv[2]
+    os.makedirs(outdir, exist_ok=True)
+    jobs = []
+    for line in open(exp):
+        line = line.strip()
+        if not line or line.startswith("#"):
+            continue
+        name, ndim, dims, pts, dtype, opts = [s.strip() for s in line.split("|")]
+        ndim = int(ndim)
+        d = [int(x) for x in dims.split()]
+        if ndim == 2:
+            d = [1] + d
+        stc = os.path.join(outdir, "x%s_%s.stc" % (pts, "x".join(str(x) for x in d)))
+        if not os.path.exists(stc):
+            write_stc(stc, ndim, tuple(d), 4, PTS[pts])
+        args = (["--3d"] if ndim == 3 else []) + ["--dtype", dtype] + opts.split() + [stc]
+        jobs.append((name, ndim, d, dtype, args))
+    from concurrent.futures import ProcessPoolExecutor
+    t0 = time.time()
+    with ProcessPoolExecutor(max_workers=min(16, os.cpu_count())) as ex:
+        res = list(ex.map(_build, [j[4] for j in jobs]))
+    print("built in %.0f s" % (time.time() - t0), flush=True)
+    kerns = []
+    for j, (ok, info) in zip(jobs, res):
+        if not ok:
+            print(j[0], "BUILD FAILED", info.splitlines()[-1] if info else "", flush=True)
+            continue
+        kerns.append((j, drs.Kernel(j[4])))
+    import torch
+    bufs = {}
+    out = open(os.path.join(outdir, "explore.jsonl"), "a")
+    # copy ceiling
+    for nbytes in (1 << 30, 4 << 30):
+        a = torch.empty(nbytes // 4, dtype=torch.float32, device="cuda").uniform_()
+        b = torch.empty_like(a)
+        for _ in range(3):
+            b.copy_(a)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(10):
+            b.copy_(a)
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / 10
+        print("copy %d MiB: %.3f ms  %.0f GB/s (read+write)" % (nbytes >> 20, ms, 2 * nbytes / ms / 1e6), flush=True)
+        out.write(json.dumps(dict(name="copy_%dMiB" % (nbytes >> 20), ms=ms, GBps=2 * nbytes / ms / 1e6)) + "\n")
+        del a, b
+    for (name, ndim, d, dtype, args), k in kerns:
+        key = (tuple(d), dtype)
+        if key not in bufs:
+            bufs.clear()
+            torch.cuda.empty_cache()
+            tdt = torch.float32 if dtype == "fp32" else torch.float64
+            shape = tuple(d) if ndim == 3 else tuple(d[1:])
+            bufs[key] = (torch.rand(shape, dtype=tdt, device="cuda"), torch.zeros(shape, dtype=tdt, device="cuda"))
+        A, B = bufs[key]
+        if name.startswith("gold"):
+            for _ in range(2):
+                k.launch_gold(A.data_ptr(), B.data_ptr())
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(4):
+                k.launch_gold(A.data_ptr(), B.data_ptr())
+            e1.record()
+            torch.cuda.synchronize()
+            n, ms = 4, e0.elapsed_time(e1)
+        else:
+            n, ms = k.run_timed(A.data_ptr(), B.data_ptr(), iterations=8 * k.info["step"], warmup=4, stream=torch.cuda.current_stream().cuda_stream)
+        dur = ms / n
+        gbs = k.bytes_per_launch() / dur / 1e6
+        gst = k.updates_per_launch() / dur / 1e6
+        rec = dict(name=name, dims=d, dtype=dtype, args=" ".join(args[:-1]), ms=dur, GBps=gbs, frac=gbs / 8000, GStencil=gst, lds=k.info["lds_bytes"], threads=k.info["threads"], grid=k.info["grid"])
+        out.write(json.dumps(rec) + "\n")
+        out.flush()
+        print("%-28s %8.3f ms %6.0f GB/s (%4.1f%%) %7.1f GSt  lds=%6d grid=%d" % (name, dur, gbs, gbs / 80, gst, k.info["lds_bytes"], k.info["grid"]), flush=True)
+
+
+if __name__ == "__main__":
+    main()

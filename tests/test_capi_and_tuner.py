@@ -1,0 +1,96 @@
+"""C-ABI surface (loads, exports every symbol include/drstencil_amd.h declares; no compute
+without a GPU), host helpers, and the tuner's space/naming logic."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+import drstencil_amd as drs
+import oracle
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, "include", "drstencil_amd.h")).read()
+    declared = set(re.findall(r"\b(drs_[a-z0-9_]+)\s*\(", hdr))
+    declared -= {"drs_spec", "drs_kernel"}
+    L = ctypes.CDLL(drs.LIB_PATH)
+    for sym in sorted(declared):
+        assert hasattr(L, sym), sym
+    assert declared == set(drs.EXPORTS)
+    assert drs.lib().drs_version().startswith(b"drstencil-amd")
+
+
+def test_missing_library_fails_loudly(monkeypatch, tmp_path):
+    monkeypatch.setattr(drs, "_lib", None)
+    monkeypatch.setattr(drs, "LIB_PATH", str(tmp_path / "nope.so"))
+    with pytest.raises(drs.NativeLibraryMissing):
+        drs.lib()
+
+
+def test_fill_random_and_check_error_match_oracle():
+    for dt in (np.float64, np.float32):
+        a = drs.fill_random(np.empty((7, 9, 11), dt))
+        b = oracle.fill_random((7, 9, 11), dt)
+        assert np.array_equal(a, b)
+    assert a.dtype == np.float32
+    a64 = drs.fill_random(np.empty(4, np.float64))
+    assert a64[0] == 0.84018771754595234
+    ref = np.random.default_rng(0).random((9, 10, 11))
+    out = ref.copy(); out[4, 5, 6] += 2e-3; out[0, 0, 0] = 9
+    m = drs.check_error(out, ref, 1)
+    assert m["max_abs"] == pytest.approx(2e-3) and m["max_idx"] == (4 * 10 + 5) * 11 + 6
+    assert m["rms"] == pytest.approx(np.sqrt(4e-6 / (7 * 8 * 9)))
+    m2 = drs.check_error(ref[0], ref[0], 2)
+    assert m2["max_abs"] == 1e-13 and m2["rms"] == 0
+
+
+def test_kernel_build_reports_generator_errors(tmp_path):
+    with pytest.raises(drs.KernelBuildError) as e:
+        drs.Kernel(["--3d", str(tmp_path / "missing.stc")])
+    assert "Error opening stencil file." in str(e.value)
+    stc = os.path.join(ROOT, "benchmarks", "3d9pt_cross", "3d9pt_cross.stc")
+    with pytest.raises(drs.KernelBuildError) as e:
+        drs.Kernel(["--3d", stc])
+    assert "No data to reuse" in str(e.value)
+
+
+def test_kernel_info_and_work_model():
+    stc = os.path.join(ROOT, "tests", "stc", "smoke3.stc")
+    k = drs.Kernel(["--3d", "--dtype", "fp32", stc])   # built by build(); cross-compiles if not
+    i = k.info
+    assert (i["L"], i["M"], i["N"], i["halo"], i["step"], i["dtype"]) == (40, 36, 256, 1, 1, "fp32")
+    assert k.updates_per_launch() == 38 * 34 * 254
+    assert k.bytes_per_launch() == 2 * 4 * 40 * 36 * 256
+    assert os.path.exists(k.path) and k.path.endswith(".so")
+
+
+def test_tuner_space_and_naming():
+    from drstencil_amd.tuner import tuning as t
+    t.order, t.ndim, t.elem_bytes = 1, 3, 4
+    v = (2, 1, (16, 8), 8, 4, False, 1, False, 1, 5, False, "lds", 1)
+    # reference naming/command-line scheme (benchmarks/3d7pt_star/tuning.py:40-78) + our suffix
+    assert t.cfgToString(v).startswith("fu2d1bx16y8sn8u4cmx1cmy1mf5")
+    assert t.cfgToCommandLine(v).startswith(" --bx 16 --by 8 --sn 8 --stream-unroll 4 --step 2 --dist 1 --cyclic-merge-x 1 --cyclic-merge-y 1 --merge-forward 5")
+    vp = v[:10] + (True, "dpp", 0)
+    assert t.cfgToString(vp).startswith("fu2d1bx16y8sn8u4cmx1cmy1mf5p")
+    space = t.enumerate_space((1,))
+    assert len(space) > 100
+    assert all(t.FilterParams(s) for s in space)
+    names = [t.cfgToString(s) for s in space]
+    assert len(set(names)) == len(names)
+    # filter rules: dist range, LDS budget, wavefront multiple
+    assert not t.FilterParams((2, 3, (64, 4), 64, 4, True, 4, True, 4, 5, False, "lds", 1))   # dist > step*order
+    assert not t.FilterParams((1, 1, (16, 2), 64, 4, True, 4, True, 4, 5, False, "lds", 1))   # 32 lanes: half a wave
+    assert not t.FilterParams((1, 1, (256, 4), 64, 4, True, 4, True, 8, 5, False, "lds", 1))  # LDS over 160 KiB
+    assert t.FilterParams((1, 1, (64, 4), 64, 4, True, 4, True, 4, 5, False, "lds", 1))
+    # every configuration of the space is accepted by the generator
+    stc = os.path.join(ROOT, "benchmarks", "3d7pt_star", "3d7pt_star.stc")
+    import random
+    random.seed(0)
+    for s in random.sample(space, 25):
+        rc, msg, src = drs.generate(["--3d", "--dtype", "fp32"] + t.cfgToCommandLine(s).split() + [stc])
+        assert rc == 0 and src, (t.cfgToString(s), msg)

@@ -1,0 +1,92 @@
+"""N > 1 path on CPU: world_size-2 (and 3) gloo runs of the z-slab decomposition with the
+oracle sweep standing in for the HIP kernel, checked bit-exactly against the single-domain
+oracle run.  Exercises SlabPlan's index bookkeeping, ghost planes of both ping-pong
+buffers, the frozen global ring and the send/recv pairing."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+import oracle
+from drstencil_amd.multigpu import SlabPlan, SlabRun, slab_bounds
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+STC = os.path.join(ROOT, "tests", "stc", "smoke3.stc")   # 40 x 36 x 256, 3d7pt_star
+
+
+def test_slab_plan_covers_every_interior_plane_once():
+    for L, H, R in [(40, 1, 2), (40, 2, 3), (1024, 1, 8), (1024, 2, 8), (37, 3, 4), (64, 1, 1)]:
+        seen = np.zeros(L, int)
+        for r in range(R):
+            p = SlabPlan(L, H, R, r)
+            assert (p.z0, p.z1) == slab_bounds(L, R, r)
+            for a, b in p.outputs():
+                seen[a:b] += 1
+            if p.has_up:
+                assert p.send_up == (H, 2 * H) and p.recv_up == (0, H)
+            if p.has_dn:
+                assert p.send_dn[1] == p.Lloc - H and p.recv_dn[1] == p.Lloc
+        assert np.all(seen[H:L - H] == 1) and not seen[:H].any() and not seen[L - H:].any()
+    with pytest.raises(ValueError):
+        SlabPlan(16, 3, 4, 1)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, step, iterations, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    spec = oracle.Spec(STC, 3, step)
+    L, M, N = spec.dims
+    H = spec.halo
+
+    def sweep(src, dst, stream):
+        vs = oracle.Spec(STC, 3, step)
+        vs.set_dims(src.shape[0], M, N)
+        a, b = src.numpy(), dst.numpy()
+        assert a.flags.c_contiguous and b.flags.c_contiguous
+        oracle.sweep(vs, a, b, 1)
+
+    run = SlabRun(torch, dist, L, M, N, H, step, iterations, rank, world, sweep, torch.device("cpu"), torch.float32)
+    full = oracle.fill_random((L, M, N), np.float32)
+    run.load_global(lambda lo, hi: full[lo:hi])
+    n = run.run()
+    q.put((rank, n, run.plan.z0, run.plan.z1, run.owned(run.A).numpy().copy(), run.owned(run.B).numpy().copy()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,step,iterations", [(2, 1, 4), (2, 2, 4), (3, 1, 5)])
+def test_slab_decomposition_matches_single_domain(world, step, iterations):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, step, iterations, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    parts = [q.get(timeout=180) for _ in range(world)]
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    spec = oracle.Spec(STC, 3, step)
+    spec.iterations = iterations
+    A = oracle.fill_random(spec.shape, np.float32)
+    B = np.zeros_like(A)
+    n_ref = oracle.run(spec, A, B, contract=1)
+    for rank, n, z0, z1, a, b in parts:
+        assert n == n_ref
+        assert np.array_equal(a, A[z0:z1]), "rank %d buffer A differs" % rank
+        assert np.array_equal(b, B[z0:z1]), "rank %d buffer B differs" % rank
