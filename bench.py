@@ -33,17 +33,26 @@ WORKLOADS = {
 }
 # tuned generator options per workload (see profiles/ and DESIGN.md; found with drstencil_amd/tuner)
 TUNED = {
-    "c4": ["--3d", "--dtype", "fp32", "--bx", "64", "--by", "4", "--block-merge-x", "4", "--block-merge-y", "8", "--sn", "8", "--xcd-remap", "2"],
-    "c3": ["--3d", "--dtype", "fp32", "--bx", "64", "--by", "4", "--block-merge-x", "4", "--block-merge-y", "8", "--sn", "8", "--xcd-remap", "1"],
+    # 2 time steps per launch on chip (temporal blocking); 66 lanes x 4 points = 264 columns, 256 owned:
+    # 4 tiles cover N = 1024 exactly; 15 x 2 = 30 rows, 26 owned
+    "c4": ["--3d", "--dtype", "fp32", "--step", "2", "--temporal", "1", "--prefetch", "--bx", "66", "--by", "15",
+           "--block-merge-x", "4", "--block-merge-y", "2", "--sn", "32", "--xcd-remap", "0"],
+    "c3": ["--3d", "--dtype", "fp32", "--step", "2", "--temporal", "1", "--prefetch", "--bx", "66", "--by", "15",
+           "--block-merge-x", "4", "--block-merge-y", "2", "--sn", "16", "--xcd-remap", "0"],
     "c2": ["--dtype", "fp32", "--bx", "64", "--by", "4", "--block-merge-x", "4", "--block-merge-y", "8", "--xcd-remap", "0"],
     "c5": ["--dtype", "fp64", "--bx", "64", "--by", "4", "--block-merge-x", "2", "--block-merge-y", "8", "--xcd-remap", "0"],
+}
+# the same workloads without temporal blocking (one time step per launch): highest roofline fraction
+STEP1 = {
+    "c4": ["--3d", "--dtype", "fp32", "--bx", "64", "--by", "4", "--block-merge-x", "4", "--block-merge-y", "8", "--sn", "8", "--xcd-remap", "2"],
+    "c3": ["--3d", "--dtype", "fp32", "--bx", "64", "--by", "4", "--block-merge-x", "4", "--block-merge-y", "8", "--sn", "8", "--xcd-remap", "1"],
 }
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak (MI355X_MICROARCH.md: 8.0 TB/s spec)
 
 
 def kernel_arg_sets():
     """Kernels bench.py needs; prebuilt by __graft_entry__.build()."""
-    return [TUNED[w] + [WORKLOADS[w]["stc"]] for w in ("c4", "c3", "c2", "c5")]
+    return [TUNED[w] + [WORKLOADS[w]["stc"]] for w in ("c4", "c3", "c2", "c5")] + [STEP1[w] + [WORKLOADS[w]["stc"]] for w in ("c4", "c3")]
 
 
 def cpu_baseline(workload, step, budget_s=20.0):
@@ -108,8 +117,11 @@ def main():
     spec = drs.Spec(w["stc"], w["ndim"], int(opts[opts.index("--step") + 1]) if "--step" in opts else 1)
     L, M, N = spec.dims
     H, step, iters = spec.halo, spec.step, spec.iterations
+    kern1 = None
     if world == 1:
         kern = drs.Kernel(opts + [w["stc"]])
+        if args.workload in STEP1 and not args.kernel_args:
+            kern1 = drs.Kernel(STEP1[args.workload] + [w["stc"]])
     else:
         from drstencil_amd.multigpu import HipSweep, SlabPlan, SlabRun
         assert w["ndim"] == 3, "slab decomposition is implemented for 3D specs"
@@ -158,6 +170,15 @@ def main():
         assert n == launches_per_step * args.steps
         kinfo = kern.info
         parallelism = "1 GPU"
+        step1 = None
+        if kern1 is not None:
+            # side measurement: the one-step-per-launch kernel on the same grid (reference protocol:
+            # warm-up launches, then the timed ping-pong loop bracketed by HIP events)
+            n1, ms1 = kern1.run_timed(A.data_ptr(), B.data_ptr(), iterations=8, warmup=4, stream=stream.cuda_stream)
+            bytes1 = kern1.bytes_per_launch()
+            step1 = {"generator_options": " ".join(STEP1[args.workload]), "GStencil_per_s": kern1.updates_per_launch() * n1 / (ms1 * 1e-3) / 1e9,
+                     "avg_launch_ms": ms1 / n1, "achieved_GBps": bytes1 * n1 / (ms1 * 1e-3) / 1e9,
+                     "roofline_frac": bytes1 * n1 / (ms1 * 1e-3) / 1e9 / HBM_PEAK_GBS}
     else:
         run = SlabRun(torch, dist, L, M, N, H, step, iters, rank, world, sweep, dev, tdt)
         g = torch.Generator(device=dev).manual_seed(1 + rank)
@@ -184,6 +205,7 @@ def main():
         el, ev_ms = float(t[0]), float(t[1])
         kinfo = sweep.kernel(run.plan.interior[1] - run.plan.interior[0]).info
         parallelism = "z-slab x%d, RCCL send/recv halo, overlapped" % world
+        step1 = None
 
     if rank == 0:
         total_launches = launches_per_step * args.steps
@@ -206,6 +228,7 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                          "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": avg_launch_s * 1e3},
         }
+        out["step1_kernel"] = step1
         if not args.no_cpu_baseline and world == 1:
             sys.path.insert(0, ROOT)
             out["cpu_baseline"] = cpu_baseline(args.workload, step)

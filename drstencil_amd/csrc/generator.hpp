@@ -77,6 +77,8 @@ MI355X options:
 --schedule <scatter|window>  scatter (default): every arriving plane adds its taps to the
                         partial sums of the output planes in flight (carried in VGPRs);
                         window: keep a rotating register window per resident plane.
+--temporal <0|1>        With --step n > 1: run the one-step stencil n times on chip (temporal blocking,
+                        intermediate planes never leave the CU) instead of the fused stencil.
 --lazy-rims <0|1>       Read LDS rims when first needed (1) or when a plane arrives (0).
 --xcd-remap <0|1|2>     workgroup to tile mapping: 0 dispatch order, 1 contiguous chunk of tiles
                         per XCD, 2 one x-y band per XCD with all XCDs on the same stream block
@@ -131,6 +133,7 @@ inline GenResult generate(const std::vector<std::string> &args /* argv[1..] */) 
         else if (a == "--dtype") { if (!str_opt(o.dtype)) break; }
         else if (a == "--xrim") { if (!str_opt(o.xrim)) break; }
         else if (a == "--schedule") { if (!str_opt(o.schedule)) break; }
+        else if (a == "--temporal") { if (!int_opt(o.temporal, nullptr)) break; }
         else if (a == "--lazy-rims") { if (!int_opt(o.lazy_rims, nullptr)) break; }
         else if (a == "--xcd-remap") { if (!int_opt(o.xcd_remap, nullptr)) break; }
         else if (a == "--nt-store") { if (!int_opt(o.nt_store, nullptr)) break; }
@@ -160,6 +163,9 @@ inline GenResult generate(const std::vector<std::string> &args /* argv[1..] */) 
     std::string cmdline;
     for (size_t i = 0; i + 1 < args.size(); i++) cmdline += (i ? " " : "") + args[i];
     HipEmitter em(res.plan, o);
+    if (em.lds_bytes() > 160 * 1024) {   // gfx950: 160 KiB of LDS per workgroup
+        res.messages += "Invalid configuration!\n"; res.exit_code = 255; res.plan.error = "tile needs more than 160 KiB of LDS"; return res;
+    }
     res.source = em.source(stcfile, cmdline);
     res.out_name = o.out_name;
     res.emitted = true;

@@ -55,6 +55,7 @@ struct GenOptions {
     int waves_per_eu = 0;        // __launch_bounds__ second argument (0 = unset)
     int lds_pad = 0;             // extra dwords of padding per LDS row
     int ref_defaults = 0;        // 1: keep the reference's 16x16x16 defaults instead of MI355X ones
+    int temporal = 0;            // step > 1: apply the one-step stencil `step` times on chip instead of the fused stencil
     std::string schedule = "scatter";  // scatter: partial sums carried in VGPRs; window: rotating register windows
     int tile_order = 0;          // 0: x fastest, then y, then stream blocks; 1: stream blocks fastest last->first
 };
@@ -74,7 +75,12 @@ struct KernelPlan {
     int DS = 1, DY = 1, DX = 1;          // dims in role order
     long stride_s = 0, stride_y = 0;     // element strides (x is contiguous)
     int iterations = 0, step = 1, halo = 0, dist = 0, range = 0;
-    std::vector<Tap> taps;   // gold order (lexicographic k, j, i)
+    std::vector<Tap> taps;   // taps the kernel applies per stage, gold order (lexicographic k, j, i)
+    std::vector<Tap> gtaps;  // taps of the fused stencil (gold kernel, reference semantics)
+    int stages = 1;          // on-chip time steps per launch (temporal blocking); 1 = apply `taps` once
+    int oym = 0, oyp = 0;    // rows at the tile's y edges that are not owned (halo of all stages)
+    int AL = 0;              // columns at each x edge of the lane tile that are not owned (stages > 1)
+    int OX = 0;              // columns owned per tile
     int zl = 0, zh = 0, hym = 0, hyp = 0, hxm = 0, hxp = 0;
     // geometry
     int BX = 64, BY = 4, VX = 4, RY = 1, SN = 16;

@@ -7,6 +7,7 @@
 // the 2D streaming kernel (codegen_2d.hpp:125).
 #pragma once
 #include <algorithm>
+#include <cmath>
 #include <string>
 #include "plan.hpp"
 
@@ -64,13 +65,28 @@ inline KernelPlan make_plan(const Stencil &st, const GenOptions &o_in, const std
     const int mx = std::max(o.bmx, o.cmx), my = std::max(o.bmy, o.cmy);
 
     // role mapping (streamed, row, col)
-    for (auto &e : st.pts.v) {
+    auto to_tap = [&](const std::pair<Pt, double> &e, bool full_precision) {
         Tap t;
         if (st.ndim == 3) { t.ds = e.first.k; t.dy = e.first.j; t.dx = e.first.i; }
         else if (stream2d) { t.ds = e.first.j; t.dy = 0; t.dx = e.first.i; }
         else { t.ds = 0; t.dy = e.first.j; t.dx = e.first.i; }
-        t.coef = coef_text(e.second);
-        p.taps.push_back(t);
+        if (full_precision) { char b[64]; snprintf(b, sizeof b, "%.17g", e.second); t.coef = b; }
+        else t.coef = coef_text(e.second);
+        return t;
+    };
+    for (auto &e : st.pts.v) p.gtaps.push_back(to_tap(e, false));
+    // Temporal blocking applies the ONE-STEP stencil `step` times on chip.  It equals the
+    // reference's algebraically fused stencil (drstencil.hpp:262-282) up to rounding, provided
+    // the 6-digit rounding of the fused coefficients (drstencil.hpp:192) is a no-op; otherwise
+    // the fused single-pass kernel is emitted (exact reference arithmetic).
+    bool temporal = o.temporal && st.step > 1;
+    if (temporal)
+        for (auto &e : st.pts.v)
+            if (std::fabs(coef_rounded(e.second) - e.second) > 1e-12 * std::fabs(e.second)) temporal = false;
+    p.stages = temporal ? st.step : 1;
+    if (temporal) for (auto &e : st.base.v) p.taps.push_back(to_tap(e, true));
+    else p.taps = p.gtaps;
+    for (auto &t : p.taps) {
         p.zl = std::min(p.zl, t.ds); p.zh = std::max(p.zh, t.ds);
         p.hym = std::max(p.hym, -t.dy); p.hyp = std::max(p.hyp, t.dy);
         p.hxm = std::max(p.hxm, -t.dx); p.hxp = std::max(p.hxp, t.dx);
@@ -83,7 +99,7 @@ inline KernelPlan make_plan(const Stencil &st, const GenOptions &o_in, const std
     if (st.M <= 0 || st.N <= 0 || (st.ndim == 3 && st.L <= 0)) { p.error = "grid size missing in the .stc"; return p; }
     // The interior guard is Halo in every dim (codegen.hpp:654); a tap reaching further
     // than Halo would read outside the arrays in the reference.
-    if (std::max({-p.zl, p.zh, p.hym, p.hyp, p.hxm, p.hxp}) > st.halo) { p.error = "a tap reaches beyond Halo (outermost-dim order)"; return p; }
+    if (p.stages * std::max({-p.zl, p.zh, p.hym, p.hyp, p.hxm, p.hxp}) > st.halo) { p.error = "a tap reaches beyond Halo (outermost-dim order)"; return p; }
     // evaluated on the options as given (reference defaults for the unset ones), so the
     // error behaviour is the reference's own
     if (reference_invalid(st, o_in, std::max(o_in.bmx, o_in.cmx), std::max(o_in.bmy, o_in.cmy))) { p.error = "tile does not cover the halo"; return p; }
@@ -104,17 +120,23 @@ inline KernelPlan make_plan(const Stencil &st, const GenOptions &o_in, const std
     p.TY = p.BY * p.RY;
     p.PADL = p.hxm ? round_up(p.hxm, vl) : 0;
     p.PADR = p.hxp ? round_up(p.hxp, vl) : 0;
-    p.OY = p.has_y ? p.TY - p.hym - p.hyp : 1;
+    p.oym = p.stages * p.hym; p.oyp = p.stages * p.hyp;
+    p.OY = p.has_y ? p.TY - p.oym - p.oyp : 1;
     if (p.OY < 1) { p.error = "tile has no rows left after the y halo"; return p; }
     if (p.PADL > p.TX || p.PADR > p.TX) { p.error = "x halo wider than the tile"; return p; }
+    // stages > 1: intermediate planes have no x halo, so each extra stage loses hx columns per side
+    p.AL = (p.stages > 1) ? round_up((p.stages - 1) * std::max(p.hxm, p.hxp), vl) : 0;
+    p.OX = p.TX - 2 * p.AL;
+    if (p.OX < 1) { p.error = "tile has no columns left after the x halo of the fused stages"; return p; }
     const int H = st.halo;
-    p.NBX = std::max(1, ceil_div(p.DX - H, p.TX));
+    p.NBX = std::max(1, ceil_div(p.DX - H, p.OX));
     p.NBY = p.has_y ? std::max(1, ceil_div(p.DY - H, p.OY)) : 1;
     p.NBS = p.has_s ? std::max(1, ceil_div(p.DS - 2 * H, p.SN)) : 1;
     if (p.DX - 2 * H < 1 || (p.has_y && p.DY - 2 * H < 1) || (p.has_s && p.DS - 2 * H < 1)) { p.error = "grid has no interior"; return p; }
 
     p.SROW = p.PADL + p.TX + p.PADR + o.lds_pad;
     p.SROWS = p.has_y ? p.TY + p.hym + p.hyp : 1;
+    if (p.stages > 1) p.NSLOT = p.stages;
     return p;
 }
 

@@ -81,6 +81,7 @@ struct Stencil {
     int iterations = 0;           // reference leaves it uninitialised when the .stc has no `iterations`
     bool iterations_set = false;
     CoefTable pts;                // after fuse(): the fused table (unrounded doubles)
+    CoefTable base;               // the table as read from the .stc (one time step)
     int step = 1;
     int halo = 0;                 // "order"
     int dist = 0;
@@ -119,6 +120,7 @@ struct Stencil {
     // stencil <- stencil convolved with itself `s` times; depth-first in table order.
     void fuse(int s) {
         step = s;
+        base = pts;
         CoefTable out;
         fuse_walk(out, Pt(), 1.0, s);
         pts = out;

@@ -42,3 +42,17 @@ def pytest_sessionstart(session):
     jobs.append(["--dtype", "fp32", "--streaming", "--xrim", "dpp", stcp("t2_box25")])
     for j in jobs:
         drs.Kernel(j)
+    # slab-view kernels of test_slab_decomposition_on_one_gpu (compiled here, before HIP is up)
+    import tempfile
+    from drstencil_amd.multigpu import HipSweep, SlabPlan
+    global SLAB_CACHE
+    SLAB_CACHE = os.path.join(ROOT, "drstencil_amd", "_kcache")
+    for world, opts, halo in [(2, ["--3d", "--dtype", "fp32", "--sn", "8"], 1), (3, ["--3d", "--dtype", "fp32", "--step", "2", "--sn", "16"], 2),
+                              (2, ["--3d", "--dtype", "fp32", "--step", "2", "--temporal", "1", "--by", "8", "--block-merge-y", "4", "--sn", "16", "--prefetch"], 2)]:
+        sw = HipSweep(stcp("t3_star"), opts, SLAB_CACHE)
+        drs.Kernel(opts + [stcp("t3_star")])
+        for r in range(world):
+            sp = SlabPlan(70, halo, world, r)
+            for v in (sp.top, sp.bot, sp.interior):
+                if v is not None and v[1] - v[0] > 2 * halo:
+                    sw.kernel(v[1] - v[0])

@@ -49,6 +49,17 @@ _add("2d25_fp64_step2", 2, "t2_box25", "--dtype", "fp64", "--step", "2")
 _add("2dodd_fp32_it5", 2, "t2_odd", "--dtype", "fp32")
 _add("2dodd_fp64_step2_stream", 2, "t2_odd", "--dtype", "fp64", "--step", "2", "--streaming")
 
+# temporal blocking (on-chip multi-step): equal to the fused stencil up to rounding
+_add("3d7_fp32_t2", 3, "t3_star", "--dtype", "fp32", "--step", "2", "--temporal", "1", "--by", "8", "--block-merge-y", "4", "--sn", "16", "--prefetch")
+_add("3d7_fp64_t2_lds", 3, "t3_star", "--dtype", "fp64", "--step", "2", "--temporal", "1", "--by", "8", "--block-merge-y", "4", "--sn", "9", "--xrim", "lds")
+_add("3d7_fp32_t3", 3, "t3_star", "--dtype", "fp32", "--step", "3", "--temporal", "1", "--bx", "34", "--by", "15", "--block-merge-y", "2", "--sn", "16", "--prefetch")
+_add("3d7_fp32_t2_b66", 3, "t3_star", "--dtype", "fp32", "--step", "2", "--temporal", "1", "--bx", "66", "--by", "15", "--block-merge-y", "2", "--sn", "32", "--prefetch", "--xcd-remap", "0")
+_add("3d9x_fp64_t2", 3, "t3_cross", "--dtype", "fp64", "--dist", "2", "--step", "2", "--temporal", "1", "--by", "8", "--block-merge-y", "4")
+_add("3dodd_fp32_t2_falls_back_to_fused", 3, "t3_odd", "--dtype", "fp32", "--step", "2", "--temporal", "1")
+_add("2d5_fp32_t2_tile", 2, "t2_star", "--dtype", "fp32", "--step", "2", "--temporal", "1", "--by", "8", "--block-merge-y", "4")
+_add("2d5_fp64_t3_stream", 2, "t2_star", "--dtype", "fp64", "--step", "3", "--temporal", "1", "--streaming", "--sn", "24", "--prefetch")
+_add("2d25_fp64_t2_tile", 2, "t2_box25", "--dtype", "fp64", "--step", "2", "--temporal", "1", "--by", "8", "--block-merge-y", "4")
+
 SMOKE = ("smoke3", 3, stc("smoke3"), ["--3d", "--dtype", "fp32"])
 
 # BASELINE.json configs at full size: (id, ndim, stc, options)
@@ -58,6 +69,9 @@ FULL = [
     ("C3_3d7pt_512_fp32", 3, os.path.join(CFG, "c3_3d7pt_star_512.stc"), ["--3d", "--dtype", "fp32"]),
     ("C3_3d7pt_512_fp32_step2", 3, os.path.join(CFG, "c3_3d7pt_star_512.stc"), ["--3d", "--dtype", "fp32", "--step", "2"]),
     ("C4_3d7pt_1024_fp32", 3, os.path.join(CFG, "c4_3d7pt_star_1024.stc"), ["--3d", "--dtype", "fp32"]),
+    ("C4_3d7pt_1024_fp32_temporal2", 3, os.path.join(CFG, "c4_3d7pt_star_1024.stc"),
+     ["--3d", "--dtype", "fp32", "--step", "2", "--temporal", "1", "--prefetch", "--bx", "66", "--by", "15", "--block-merge-x", "4",
+      "--block-merge-y", "2", "--sn", "32", "--xcd-remap", "0"]),
     ("C5_2d25pt_16384_fp64", 2, os.path.join(CFG, "c5_2d25pt_box_16384.stc"), ["--dtype", "fp64"]),
 ]
 

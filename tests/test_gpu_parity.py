@@ -7,6 +7,7 @@ Bar: fp32 within 1e-6 relative (BASELINE.json north_star), fp64 within 1e-12; ev
 the generator emits keeps the gold summation order as an FMA chain, so the tests also
 require BIT-EXACT agreement with the oracle's contracted mode."""
 import json
+import os
 
 import numpy as np
 import pytest
@@ -61,11 +62,19 @@ def test_hip_vs_oracle_seeded(torch_cuda, cid, ndim, stc, opts):
     n_ref = oracle.run(spec, A_ref, B_ref, contract=1)
     n, A, B = run_hip(torch, kern, A0, B0)
     assert n == n_ref
+    temporal = "--temporal" in opts and kern.info.get("stages", 1) > 1
+    h = spec.halo
+    ring = np.ones(A.shape, bool)
+    ring[tuple(slice(h, s - h) for s in A.shape)] = False
     for got, ref in ((A, A_ref), (B, B_ref)):
         m = oracle.check(spec, got, ref)
         assert m["max_rel"] <= REL_TOL[dt], (cid, m)
-        # ring (never written by the reference) must be untouched, interior bit-exact
-        assert np.array_equal(got, ref), (cid, "not bit-exact", m)
+        # ring (never written by the reference) must be untouched
+        assert np.array_equal(got[ring], ref[ring]), cid
+        # single-pass kernels keep the gold order as an FMA chain: bit-exact.  Temporal blocking
+        # re-associates (it applies the one-step stencil `step` times): tolerance only.
+        if not temporal:
+            assert np.array_equal(got, ref), (cid, "not bit-exact", m)
     # the emitted gold kernel agrees too (the reference's own check path)
     n, Ag, Bg = run_hip(torch, kern, A0, B0, gold=True)
     assert np.array_equal(Ag, A_ref) and np.array_equal(Bg, B_ref)
@@ -120,8 +129,15 @@ def test_full_size_properties(torch_cuda, cid, ndim, stc, opts):
     ng = kern.run(Ag.data_ptr(), Bg.data_ptr(), gold=True)
     torch.cuda.synchronize()
     assert n == ng == i["iterations"] // (2 * i["step"]) * 2 + (2 if i["iterations"] % (2 * i["step"]) else 0)
-    assert torch.equal(A, Ag), cid
-    assert torch.equal(B, Bg), cid
+    if "--temporal" in opts:
+        # temporal blocking vs the fused gold kernel: equal up to rounding (fp32: 1e-6 relative)
+        inner0 = tuple(slice(i["halo"], s - i["halo"]) for s in shape)
+        for x, y in ((A, Ag), (B, Bg)):
+            rel = ((x[inner0] - y[inner0]).abs() / y[inner0].abs().clamp_min(1e-30)).max().item()
+            assert rel <= REL_TOL[dt], (cid, rel)
+    else:
+        assert torch.equal(A, Ag), cid
+        assert torch.equal(B, Bg), cid
     h = i["halo"]
     inner = tuple(slice(h, s - h) for s in shape)
     ringA = A.clone(); ringA[inner] = 0
@@ -144,7 +160,14 @@ def test_full_size_properties(torch_cuda, cid, ndim, stc, opts):
     kern.launch(A0.data_ptr(), B.data_ptr())
     torch.cuda.synchronize()
     got = B[h:nsl - h].cpu().numpy()
-    assert np.array_equal(got, dst[h:nsl - h]), cid
+    if "--temporal" in opts:
+        ref = dst[h:nsl - h]
+        inner1 = tuple(slice(h, s - h) for s in got.shape[1:])
+        sel = (slice(None),) + inner1
+        rel = np.max(np.abs(got[sel].astype(np.float64) - ref[sel]) / np.maximum(np.abs(ref[sel]), 1e-30))
+        assert rel <= REL_TOL[dt], (cid, rel)
+    else:
+        assert np.array_equal(got, dst[h:nsl - h]), cid
 
 
 def test_dpp_wave_shift_semantics(torch_cuda):
@@ -168,3 +191,90 @@ def test_native_library_is_the_path():
     assert drs.lib() is not None
     maps = open("/proc/self/maps").read()
     assert "libdrstencil_amd.so" in maps
+
+
+class _Hub:
+    """In-process stand-in for torch.distributed point-to-point (one GPU, ranks run in turn):
+    lets the product SlabRun / HipSweep code path -- slab views, boundary/interior kernels,
+    ghost planes, streams and events -- run on the single GPU of the test box.  The RCCL
+    transport itself is exercised by the driver's multi-GPU run."""
+
+    def __init__(self):
+        self.mail, self.pending = {}, []
+
+    def deliver(self):
+        still = []
+        for key, t in self.pending:
+            q = self.mail.get(key)
+            if q:
+                t.copy_(q.pop(0))
+            else:
+                still.append((key, t))
+        self.pending = still
+
+
+class _FakeDist:
+    isend, irecv = "isend", "irecv"
+
+    class P2POp:
+        def __init__(self, op, tensor, peer):
+            self.op, self.tensor, self.peer = op, tensor, peer
+
+    class _Work:
+        def wait(self):
+            return True
+
+    def __init__(self, hub, rank):
+        self.hub, self.rank = hub, rank
+
+    def batch_isend_irecv(self, ops):
+        for o in ops:
+            if o.op == "isend":
+                self.hub.mail.setdefault((self.rank, o.peer), []).append(o.tensor.clone())
+            else:
+                self.hub.pending.append(((o.peer, self.rank), o.tensor))
+        self.hub.deliver()
+        return [self._Work() for _ in ops]
+
+
+@pytest.mark.parametrize("world,opts", [
+    (2, ["--3d", "--dtype", "fp32", "--sn", "8"]),
+    (3, ["--3d", "--dtype", "fp32", "--step", "2", "--sn", "16"]),
+    (2, ["--3d", "--dtype", "fp32", "--step", "2", "--temporal", "1", "--by", "8", "--block-merge-y", "4", "--sn", "16", "--prefetch"]),
+], ids=["w2_step1", "w3_fused2", "w2_temporal2"])
+def test_slab_decomposition_on_one_gpu(torch_cuda, world, opts, tmp_path):
+    """z-slab decomposition (drstencil_amd.multigpu) with every rank on this GPU == the
+    single-domain run of the same kernel, bit for bit."""
+    import drstencil_amd as drs
+    from drstencil_amd.multigpu import HipSweep, SlabRun
+    from gpu_cases import stc as stcp
+    torch = torch_cuda
+    stc = stcp("t3_star")    # 70 x 45 x 530
+    step = _step(opts)
+    full = drs.Kernel(opts + [stc])
+    spec = oracle.Spec(stc, 3, step)
+    L, M, N = spec.dims
+    H = spec.halo
+    A0 = oracle.fill_random(spec.shape, np.float32)
+    n_ref, A_ref, B_ref = run_hip(torch, full, A0, np.zeros_like(A0))
+    hub = _Hub()
+    dev = torch.device("cuda", 0)
+    sweep = HipSweep(stc, opts, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "drstencil_amd", "_kcache"))
+    runs = [SlabRun(torch, _FakeDist(hub, r), L, M, N, H, step, spec.iterations, r, world, sweep, dev, torch.float32) for r in range(world)]
+    for r in runs:
+        r.load_global(lambda lo, hi: A0[lo:hi])
+    t, n = 0, 0
+    while t < spec.iterations:
+        for src, dst in (("A", "B"), ("B", "A")):
+            for r in runs:
+                r.launch(getattr(r, src), getattr(r, dst))
+            torch.cuda.synchronize()
+            hub.deliver()
+            assert not hub.pending
+            n += 1
+        t += 2 * step
+    assert n == n_ref
+    for r in runs:
+        p = r.plan
+        assert np.array_equal(r.owned(r.A).cpu().numpy(), A_ref[p.z0:p.z1]), "rank %d A" % r.rank
+        assert np.array_equal(r.owned(r.B).cpu().numpy(), B_ref[p.z0:p.z1]), "rank %d B" % r.rank
