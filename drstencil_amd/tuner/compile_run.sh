@@ -1,0 +1,22 @@
+#!/bin/bash
+# compile_run.sh <config-name> [<kernel-regex>]
+# Counterpart of the reference's benchmarks/<stencil>/compile_run.sh:1-5 (nvcc -arch=sm_80 +
+# `ncu --kernel-id ::dr_<name>:10 --csv --set full`): compile cu/<name>.hip for gfx950 and profile the
+# emitted program with rocprofv3.  Three runs, because gfx950 cannot count FETCH_SIZE and WRITE_SIZE
+# in one pass and counters must not be mixed with other trace domains:
+#   prof/<name>/trace  kernel durations   (--kernel-trace --stats)
+#   prof/<name>/fetch  FETCH_SIZE         (--pmc, own run)
+#   prof/<name>/write  WRITE_SIZE         (--pmc, own run)
+# The program's own stdout (timing + [Test] lines) lands in prof/<name>.log.
+set -e
+ARCH=gfx950
+name=$1
+regex=${2:-dr_}
+here=$(cd "$(dirname "$0")" && pwd)
+support=${DRS_SUPPORT:-$here/../csrc/support}
+mkdir -p bin prof
+hipcc cu/${name}.hip -O3 --offload-arch=${ARCH} -std=c++17 -ffp-contract=off -I${support} -I cu -o bin/${name}
+cd /tmp 2>/dev/null && export TMPDIR=/tmp && cd - > /dev/null
+rocprofv3 --kernel-trace --stats --output-format csv -d prof/${name}/trace -- bin/${name} > prof/${name}.log 2>&1
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --kernel-include-regex "${regex}" --output-format csv -d prof/${name}/fetch -- bin/${name} > /dev/null 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --kernel-include-regex "${regex}" --output-format csv -d prof/${name}/write -- bin/${name} > /dev/null 2>&1
