@@ -55,6 +55,16 @@ def kernel_arg_sets():
     return [TUNED[w] + [WORKLOADS[w]["stc"]] for w in ("c4", "c3", "c2", "c5")] + [STEP1[w] + [WORKLOADS[w]["stc"]] for w in ("c4", "c3")]
 
 
+def pmc_traffic(option_string):
+    """HBM bytes per launch of this exact kernel configuration from the committed rocprofv3 PMC passes
+    (FETCH_SIZE x 2 + WRITE_SIZE, profiles/traffic_by_options.json); None when it was not profiled."""
+    try:
+        m = json.load(open(os.path.join(ROOT, "profiles", "traffic_by_options.json")))
+        return m[option_string]["traffic_bytes_per_launch"]
+    except Exception:
+        return None
+
+
 def cpu_baseline(workload, step, budget_s=20.0):
     """Oracle (port) timed on the host cores on a bounded z/y-slab sample of the workload."""
     import numpy as np
@@ -225,7 +235,7 @@ def main():
                        "launches_per_step": launches_per_step, "parallelism": parallelism,
                        "kernel": "dr_" + kinfo["name"], "threads": kinfo["threads"], "lds_bytes": kinfo["lds_bytes"]},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(" ".join(opts)) if world == 1 else None,
                          "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": avg_launch_s * 1e3},
         }
         out["step1_kernel"] = step1

@@ -82,7 +82,8 @@ MI355X options:
 --lazy-rims <0|1>       Read LDS rims when first needed (1) or when a plane arrives (0).
 --xcd-remap <0|1|2>     workgroup to tile mapping: 0 dispatch order, 1 contiguous chunk of tiles
                         per XCD, 2 one x-y band per XCD with all XCDs on the same stream block
-                        (default: 2 for 3D, 0 for 2D).
+                        (default: 2 for 3D, 0 for 2D); 3 = like 2 with --zgroup <n> successive stream
+                        blocks of a tile taken by consecutive workgroups.
 --nt-store <0|1>        Non-temporal stores of the output (1 by default).
 --nt-load <0|1>         Non-temporal loads of the input.
 --waves-per-eu <num>    Second argument of __launch_bounds__.
@@ -133,6 +134,7 @@ inline GenResult generate(const std::vector<std::string> &args /* argv[1..] */) 
         else if (a == "--dtype") { if (!str_opt(o.dtype)) break; }
         else if (a == "--xrim") { if (!str_opt(o.xrim)) break; }
         else if (a == "--schedule") { if (!str_opt(o.schedule)) break; }
+        else if (a == "--zgroup") { if (!int_opt(o.zgroup, nullptr)) break; }
         else if (a == "--temporal") { if (!int_opt(o.temporal, nullptr)) break; }
         else if (a == "--lazy-rims") { if (!int_opt(o.lazy_rims, nullptr)) break; }
         else if (a == "--xcd-remap") { if (!int_opt(o.xcd_remap, nullptr)) break; }

@@ -55,6 +55,7 @@ struct GenOptions {
     int waves_per_eu = 0;        // __launch_bounds__ second argument (0 = unset)
     int lds_pad = 0;             // extra dwords of padding per LDS row
     int ref_defaults = 0;        // 1: keep the reference's 16x16x16 defaults instead of MI355X ones
+    int zgroup = 4;              // --xcd-remap 3: stream blocks of one tile taken by consecutive workgroups
     int temporal = 0;            // step > 1: apply the one-step stencil `step` times on chip instead of the fused stencil
     std::string schedule = "scatter";  // scatter: partial sums carried in VGPRs; window: rotating register windows
     int tile_order = 0;          // 0: x fastest, then y, then stream blocks; 1: stream blocks fastest last->first

@@ -10,7 +10,7 @@ sweep -> per-config generate/compile/measure -> append every improvement to dura
 rocprofv3 instead of Nsight Compute:
 
   space vector = (step, dist, (bx, by), sn, unroll, blockMergeX, mx, blockMergeY, my,
-                  mergeForward, prefetch, xrim, lazy)
+                  mergeForward, prefetch, xrim, temporal, xcd)
   * bx in {16,32,64,128,256}: lanes along x; mx in {1,2,4} points per lane (16-byte
     accesses at mx=4 fp32 / 2 fp64); by*my rows per tile; sn planes per stream block
   * LDS budget 160 KiB per CU (the reference caps at 32 KiB of A100 shared memory)
@@ -42,12 +42,21 @@ elem_bytes = 4
 
 
 def FilterParams(spaceVector):
-    step, dist, blockSize, sn, s_unroll, blockMergeX, mergeFactorX, blockMergeY, mergeFactorY, m_threshold, prefetch, xrim, lazy = spaceVector
+    step, dist, blockSize, sn, s_unroll, blockMergeX, mergeFactorX, blockMergeY, mergeFactorY, m_threshold, prefetch, xrim, temporal, xcd = spaceVector
     halo = step * order
     tx = mergeFactorX * blockSize[0]
     ty = mergeFactorY * blockSize[1] if ndim == 3 or blockSize[1] > 0 else 1
-    # LDS: (slots) x (rows + halo pads) x (row + x halo) -- an upper bound with 3 slots
-    ldsUsage = 3 * (ty + 2 * halo) * (tx + 8) * elem_bytes
+    # LDS: 2 planes (3 for an odd number of on-chip stages) x (rows + halo pads) x (row + x halo)
+    stage_halo = order if temporal else halo
+    slots = 3 if (temporal and step % 2 == 1 and step > 1) else 2
+    ldsUsage = slots * (ty + 2 * stage_halo) * (tx + 8) * elem_bytes
+    if temporal and step == 1:
+        return False
+    # the scatter schedule keeps (Range-1) partial-sum planes + one window per stage in VGPRs
+    stages = step if temporal else 1
+    vgprEstimate = stages * (3 * mergeFactorX * mergeFactorY + 2 * (mergeFactorX + mergeFactorY)) * (1 if temporal or step == 1 else step * step)
+    if vgprEstimate > 200:
+        return False
     if ldsUsage > maxLdsPerBlock:
         return False
     # dist too big or too small (reference rule; dist > halo is wrong in the reference)
@@ -56,8 +65,9 @@ def FilterParams(spaceVector):
     # the tile must keep rows after removing the y halo, and x halo must fit the tile
     if ty - 2 * halo < 1 or tx < 2 * halo:
         return False
-    # a wavefront is 64 lanes: partial waves waste lanes
-    if (blockSize[0] * max(blockSize[1], 1)) % 64 != 0:
+    # a wavefront is 64 lanes: idle lanes of the last wave may cost at most 6 % of the workgroup
+    threads = blockSize[0] * max(blockSize[1], 1)
+    if threads > 1024 or (-threads) % 64 > 0.06 * threads:
         return False
     # one row segment per wavefront instruction wants >= 128 contiguous bytes
     if tx * elem_bytes < 128:
@@ -67,6 +77,9 @@ def FilterParams(spaceVector):
         return False
     if blockMergeY and mergeFactorY == 1:
         return False
+    # odd lane counts only pay with temporal blocking (they make the owned width a power of two)
+    if blockSize[0] % 16 != 0 and not temporal:
+        return False
     # cyclic x lays points out like block x on CDNA4 (plan.hpp): keep one of them
     if not blockMergeX and mergeFactorX > 1:
         return False
@@ -74,7 +87,7 @@ def FilterParams(spaceVector):
 
 
 def cfgToCommandLine(spaceVector):
-    step, dist, blockSize, sn, s_unroll, blockMergeX, mergeFactorX, blockMergeY, mergeFactorY, m_threshold, prefetch, xrim, lazy = spaceVector
+    step, dist, blockSize, sn, s_unroll, blockMergeX, mergeFactorX, blockMergeY, mergeFactorY, m_threshold, prefetch, xrim, temporal, xcd = spaceVector
     cmd = " --bx {0} --by {1} --sn {2} --stream-unroll {3}".format(blockSize[0], blockSize[1], sn, s_unroll)
     cmd += " --step {0} --dist {1}".format(step, dist)
     if blockMergeX:
@@ -88,48 +101,59 @@ def cfgToCommandLine(spaceVector):
     cmd += " --merge-forward {0}".format(m_threshold)
     if prefetch:
         cmd += " --prefetch"
-    cmd += " --xrim {0} --lazy-rims {1}".format(xrim, lazy)
+    cmd += " --xrim {0} --xcd-remap {1}".format(xrim, xcd)
+    if temporal:
+        cmd += " --temporal 1"
     return cmd
 
 
 def cfgToString(spaceVector):
-    step, dist, blockSize, sn, s_unroll, blockMergeX, mergeFactorX, blockMergeY, mergeFactorY, m_threshold, prefetch, xrim, lazy = spaceVector
+    step, dist, blockSize, sn, s_unroll, blockMergeX, mergeFactorX, blockMergeY, mergeFactorY, m_threshold, prefetch, xrim, temporal, xcd = spaceVector
     cmd = "fu{0}d{1}bx{2}y{3}sn{4}u{5}".format(step, dist, blockSize[0], blockSize[1], sn, s_unroll)
     cmd += ("bmx{0}" if blockMergeX else "cmx{0}").format(mergeFactorX)
     cmd += ("bmy{0}" if blockMergeY else "cmy{0}").format(mergeFactorY)
     cmd += "mf{0}".format(m_threshold)
     if prefetch:
         cmd += "p"
-    cmd += "x" + xrim[0] + ("z" if lazy else "e")
+    cmd += "x" + xrim[0] + "m" + str(xcd) + ("t" if temporal else "")
     return cmd
 
 
 def enumerate_space(steps=(1,), full=False):
+    """The sweep space.  Lane counts include non-powers of two: with temporal blocking a tile owns
+    mx*bx - 2*roundup((step-1)*order, mx) columns, so e.g. bx = 66 (264 columns, 256 owned) tiles a
+    1024-wide grid exactly where bx = 64 would need a fifth tile."""
+    vec = 16 // elem_bytes
     if ndim == 3:
-        blockSizes = [(bx, by) for bx in (16, 32, 64, 128, 256) for by in (1, 2, 4, 8, 16) if bx * by <= 2 ** maxThreadsPerBlockLg2]
-        sns = [16, 32, 64, 128] if not full else [8, 16, 32, 64, 128, 256]
+        bxs = [16, 32, 34, 64, 66, 128, 130, 256]
+        bys = [1, 2, 4, 7, 8, 15, 16, 30]
+        sns = [4, 8, 16, 32, 64] if not full else [2, 4, 8, 12, 16, 24, 32, 48, 64, 128]
         mys = [1, 2, 4, 8]
     else:
-        blockSizes = [(bx, by) for bx in (64, 128, 256) for by in (1, 2, 4, 8) if bx * by <= 2 ** maxThreadsPerBlockLg2]
-        sns = [32, 64, 128, 256]
+        bxs = [64, 66, 128, 130, 256]
+        bys = [1, 2, 4, 8, 15, 16]
+        sns = [8, 16, 32, 64, 128]
         mys = [1, 2, 4, 8, 16]
-    vec = 16 // elem_bytes
+    blockSizes = [(bx, by) for bx in bxs for by in bys if bx * by <= 2 ** maxThreadsPerBlockLg2]
     space = itertools.product(
         list(steps),
         [0],                       # dist: filled per step below
         blockSizes, sns,
         [4, 8] if full else [4],   # stream unroll
         [True], [vec] if not full else [vec // 2, vec],
-        [False, True], mys,
+        [True], mys,
         [5],
-        [False, True],
-        ["lds", "dpp"],
-        [1, 0],
+        [False, True],             # prefetch
+        ["dpp"] if not full else ["lds", "dpp"],
+        [False, True],             # temporal blocking (only meaningful for step > 1)
+        [0, 2] if ndim == 3 else [0],
     )
     out = []
     for v in space:
         v = list(v)
         v[1] = v[0] * order
+        if v[8] == 1:
+            v[7] = False           # merge factor 1: cyclic == block, keep the reference's spelling
         v = tuple(v)
         if FilterParams(v):
             out.append(v)

@@ -71,22 +71,24 @@ def test_kernel_info_and_work_model():
 def test_tuner_space_and_naming():
     from drstencil_amd.tuner import tuning as t
     t.order, t.ndim, t.elem_bytes = 1, 3, 4
-    v = (2, 1, (16, 8), 8, 4, False, 1, False, 1, 5, False, "lds", 1)
+    v = (2, 1, (16, 8), 8, 4, False, 1, False, 1, 5, False, "lds", False, 2)
     # reference naming/command-line scheme (benchmarks/3d7pt_star/tuning.py:40-78) + our suffix
     assert t.cfgToString(v).startswith("fu2d1bx16y8sn8u4cmx1cmy1mf5")
     assert t.cfgToCommandLine(v).startswith(" --bx 16 --by 8 --sn 8 --stream-unroll 4 --step 2 --dist 1 --cyclic-merge-x 1 --cyclic-merge-y 1 --merge-forward 5")
-    vp = v[:10] + (True, "dpp", 0)
+    vp = v[:10] + (True, "dpp", True, 0)
     assert t.cfgToString(vp).startswith("fu2d1bx16y8sn8u4cmx1cmy1mf5p")
-    space = t.enumerate_space((1,))
+    space = t.enumerate_space((1, 2))
     assert len(space) > 100
     assert all(t.FilterParams(s) for s in space)
     names = [t.cfgToString(s) for s in space]
     assert len(set(names)) == len(names)
     # filter rules: dist range, LDS budget, wavefront multiple
-    assert not t.FilterParams((2, 3, (64, 4), 64, 4, True, 4, True, 4, 5, False, "lds", 1))   # dist > step*order
-    assert not t.FilterParams((1, 1, (16, 2), 64, 4, True, 4, True, 4, 5, False, "lds", 1))   # 32 lanes: half a wave
-    assert not t.FilterParams((1, 1, (256, 4), 64, 4, True, 4, True, 8, 5, False, "lds", 1))  # LDS over 160 KiB
-    assert t.FilterParams((1, 1, (64, 4), 64, 4, True, 4, True, 4, 5, False, "lds", 1))
+    assert not t.FilterParams((2, 3, (64, 4), 64, 4, True, 4, True, 4, 5, False, "lds", False, 2))   # dist > step*order
+    assert not t.FilterParams((1, 1, (16, 2), 64, 4, True, 4, True, 4, 5, False, "lds", False, 2))   # 32 lanes: half a wave
+    assert not t.FilterParams((1, 1, (256, 4), 64, 4, True, 4, True, 8, 5, False, "lds", False, 2))  # LDS over 160 KiB
+    assert not t.FilterParams((1, 1, (66, 15), 32, 4, True, 4, True, 2, 5, False, "dpp", False, 0))  # odd lane count without temporal
+    assert t.FilterParams((2, 2, (66, 15), 32, 4, True, 4, True, 2, 5, True, "dpp", True, 0))        # the bench configuration
+    assert t.FilterParams((1, 1, (64, 4), 64, 4, True, 4, True, 4, 5, False, "lds", False, 2))
     # every configuration of the space is accepted by the generator
     stc = os.path.join(ROOT, "benchmarks", "3d7pt_star", "3d7pt_star.stc")
     import random
