@@ -65,7 +65,7 @@ def pmc_traffic(option_string):
         return None
 
 
-def cpu_baseline(workload, step, budget_s=20.0):
+def cpu_baseline(workload, step, budget_s=15.0):
     """Oracle (port) timed on the host cores on a bounded z/y-slab sample of the workload."""
     import numpy as np
     import oracle
@@ -97,7 +97,7 @@ def cpu_baseline(workload, step, budget_s=20.0):
         oracle.sweep(spec, B, A, 1)
         sweeps += 2
         el = time.perf_counter() - t0
-        if el > budget_s or sweeps >= 64:
+        if el > budget_s or sweeps >= 400:
             break
     gst = sweeps * step * interior / el / 1e9
     return dict(value=gst, unit="GStencil/s", cores=oracle.threads(), kind="port",

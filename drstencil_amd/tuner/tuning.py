@@ -180,7 +180,7 @@ def _build(job):
         return name, False, str(e)[-400:]
 
 
-def searchSpace(stc, is3d, dtype, configs, outdir, iterations=8, budget_s=None, jobs=8, extra_opts=()):
+def searchSpace(stc, is3d, dtype, configs, outdir, iterations=8, budget_s=None, jobs=16, extra_opts=()):
     """Sweep `configs` (space vectors or raw option strings).
 
     Phase 1 generates + compiles every configuration (hipcc, parallel) BEFORE this process
