@@ -134,9 +134,8 @@ def main():
             kern1 = drs.Kernel(STEP1[args.workload] + [w["stc"]])
     else:
         from drstencil_amd.multigpu import HipSweep, SlabPlan, SlabRun
-        assert w["ndim"] == 3, "slab decomposition is implemented for 3D specs"
         sweep = HipSweep(w["stc"], opts, os.path.join(ROOT, "drstencil_amd", "_kcache"))
-        sp = SlabPlan(L, H, world, rank)
+        sp = SlabPlan(L if w["ndim"] == 3 else M, H, world, rank)
         for v in (sp.top, sp.bot, sp.interior):
             if v is not None and v[1] - v[0] > 2 * H:
                 sweep.kernel(v[1] - v[0])
@@ -190,7 +189,7 @@ def main():
                      "avg_launch_ms": ms1 / n1, "achieved_GBps": bytes1 * n1 / (ms1 * 1e-3) / 1e9,
                      "roofline_frac": bytes1 * n1 / (ms1 * 1e-3) / 1e9 / HBM_PEAK_GBS}
     else:
-        run = SlabRun(torch, dist, L, M, N, H, step, iters, rank, world, sweep, dev, tdt)
+        run = SlabRun(torch, dist, (L, M, N) if w["ndim"] == 3 else (M, N), H, step, iters, rank, world, sweep, dev, tdt)
         g = torch.Generator(device=dev).manual_seed(1 + rank)
         run.A.copy_(torch.rand(run.A.shape, dtype=tdt, device=dev, generator=g))
         for _ in range(args.warmup):

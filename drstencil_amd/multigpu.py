@@ -1,4 +1,4 @@
-"""z-slab decomposition of a 3D stencil run across the GPUs of one node, one process per
+"""Slab decomposition (z slabs in 3D, y slabs in 2D) of a stencil run across the GPUs of one node, one process per
 GPU, halo exchange by RCCL send/recv over xGMI (torch.distributed, backend "nccl" == RCCL)
 overlapped with the interior sweep on a second HIP stream.
 
@@ -63,12 +63,12 @@ class SlabPlan:
 
 
 def _write_view_stc(base_stc, ndim, L_view, cache_dir, tag):
-    """A copy of the spec with L replaced (reference .stc format)."""
-    assert ndim == 3
+    """A copy of the spec with its outermost size (L in 3D, M in 2D) replaced (reference .stc format)."""
     import re
     text = open(base_stc).read()
-    new_text, n = re.subn(r"(^|\s)L\s+\d+", lambda m: "%sL %d" % (m.group(1), L_view), text, count=1)
-    assert n == 1, "spec has no L"
+    key = "L" if ndim == 3 else "M"
+    new_text, n = re.subn(r"(^|\s)%s\s+\d+" % key, lambda m: "%s%s %d" % (m.group(1), key, L_view), text, count=1)
+    assert n == 1, "spec has no " + key
     name = os.path.basename(base_stc)[:-4]
     path = os.path.join(cache_dir, "%s_%s%d.stc" % (name, tag, L_view))
     tmp = path + ".%d.tmp" % os.getpid()
@@ -83,12 +83,13 @@ class HipSweep:
 
     def __init__(self, base_stc, opts, cache_dir):
         self.base_stc, self.opts, self.cache_dir = base_stc, list(opts), cache_dir
+        self.ndim = 3 if "--3d" in self.opts else 2
         os.makedirs(cache_dir, exist_ok=True)
         self.kernels = {}
 
     def kernel(self, Lv):
         if Lv not in self.kernels:
-            stc = _write_view_stc(self.base_stc, 3, Lv, self.cache_dir, "slabL")
+            stc = _write_view_stc(self.base_stc, self.ndim, Lv, self.cache_dir, "slabL")
             self.kernels[Lv] = drs.Kernel(self.opts + [stc])
         return self.kernels[Lv]
 
@@ -104,16 +105,18 @@ class SlabRun:
     to a contiguous [Lv, M, N] view: outputs planes [H, Lv-H) of dst_view (HipSweep in the
     product; the CPU tests inject an oracle-backed callable to check the decomposition)."""
 
-    def __init__(self, torch, dist, L, M, N, H, step, iterations, rank, world, sweep, device, dtype):
+    def __init__(self, torch, dist, dims, H, step, iterations, rank, world, sweep, device, dtype):
+        """dims = (L, M, N) for a 3D run cut along z, or (M, N) for a 2D run cut along y."""
         self.torch, self.dist = torch, dist
-        self.plan = SlabPlan(L, H, world, rank)
-        self.M, self.N, self.H, self.step, self.iterations = M, N, H, step, iterations
+        dims = tuple(dims)
+        self.plan = SlabPlan(dims[0], H, world, rank)
+        self.rest, self.H, self.step, self.iterations = dims[1:], H, step, iterations
         self.rank, self.world, self.sweep = rank, world, sweep
         self.device, self.dtype = device, dtype
         self.gpu = (device.type == "cuda")
         p = self.plan
-        self.A = torch.zeros((p.Lloc, M, N), dtype=dtype, device=device)
-        self.B = torch.zeros((p.Lloc, M, N), dtype=dtype, device=device)
+        self.A = torch.zeros((p.Lloc,) + self.rest, dtype=dtype, device=device)
+        self.B = torch.zeros((p.Lloc,) + self.rest, dtype=dtype, device=device)
         if self.gpu:
             self.main = torch.cuda.current_stream(device)
             self.comm = torch.cuda.Stream(device=device)

@@ -260,7 +260,7 @@ def test_slab_decomposition_on_one_gpu(torch_cuda, world, opts, tmp_path):
     hub = _Hub()
     dev = torch.device("cuda", 0)
     sweep = HipSweep(stc, opts, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "drstencil_amd", "_kcache"))
-    runs = [SlabRun(torch, _FakeDist(hub, r), L, M, N, H, step, spec.iterations, r, world, sweep, dev, torch.float32) for r in range(world)]
+    runs = [SlabRun(torch, _FakeDist(hub, r), (L, M, N), H, step, spec.iterations, r, world, sweep, dev, torch.float32) for r in range(world)]
     for r in runs:
         r.load_global(lambda lo, hi: A0[lo:hi])
     t, n = 0, 0

@@ -60,7 +60,7 @@ def _worker(rank, world, port, step, iterations, q):
         assert a.flags.c_contiguous and b.flags.c_contiguous
         oracle.sweep(vs, a, b, 1)
 
-    run = SlabRun(torch, dist, L, M, N, H, step, iterations, rank, world, sweep, torch.device("cpu"), torch.float32)
+    run = SlabRun(torch, dist, (L, M, N), H, step, iterations, rank, world, sweep, torch.device("cpu"), torch.float32)
     full = oracle.fill_random((L, M, N), np.float32)
     run.load_global(lambda lo, hi: full[lo:hi])
     n = run.run()
@@ -90,3 +90,49 @@ def test_slab_decomposition_matches_single_domain(world, step, iterations):
         assert n == n_ref
         assert np.array_equal(a, A[z0:z1]), "rank %d buffer A differs" % rank
         assert np.array_equal(b, B[z0:z1]), "rank %d buffer B differs" % rank
+
+
+STC2 = os.path.join(ROOT, "tests", "stc", "t2_box25.stc")   # 203 x 772, 2d25pt_box (halo 2)
+
+
+def _worker2d(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    spec = oracle.Spec(STC2, 2, 1)
+    _, M, N = spec.dims
+
+    def sweep(src, dst, stream):
+        vs = oracle.Spec(STC2, 2, 1)
+        vs.set_dims(1, src.shape[0], N)
+        oracle.sweep(vs, src.numpy(), dst.numpy(), 1)
+
+    run = SlabRun(torch, dist, (M, N), spec.halo, 1, spec.iterations, rank, world, sweep, torch.device("cpu"), torch.float64)
+    full = oracle.fill_random((M, N), np.float64)
+    run.load_global(lambda lo, hi: full[lo:hi])
+    n = run.run()
+    q.put((rank, n, run.plan.z0, run.plan.z1, run.owned(run.A).numpy().copy(), run.owned(run.B).numpy().copy()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_2d_y_slab_decomposition_matches_single_domain():
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker2d, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    parts = [q.get(timeout=180) for _ in range(world)]
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    spec = oracle.Spec(STC2, 2, 1)
+    A = oracle.fill_random(spec.shape, np.float64)
+    B = np.zeros_like(A)
+    n_ref = oracle.run(spec, A, B, contract=1)
+    for rank, n, z0, z1, a, b in parts:
+        assert n == n_ref
+        assert np.array_equal(a, A[z0:z1]) and np.array_equal(b, B[z0:z1])
