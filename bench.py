@@ -44,8 +44,8 @@ TUNED = {
 }
 # the same workloads without temporal blocking (one time step per launch): highest roofline fraction
 STEP1 = {
-    "c4": ["--3d", "--dtype", "fp32", "--bx", "64", "--by", "4", "--block-merge-x", "4", "--block-merge-y", "8", "--sn", "8", "--xcd-remap", "2"],
-    "c3": ["--3d", "--dtype", "fp32", "--bx", "64", "--by", "4", "--block-merge-x", "4", "--block-merge-y", "8", "--sn", "8", "--xcd-remap", "1"],
+    "c4": ["--3d", "--dtype", "fp32", "--bx", "64", "--by", "4", "--block-merge-x", "4", "--block-merge-y", "4", "--sn", "8", "--xcd-remap", "2"],
+    "c3": ["--3d", "--dtype", "fp32", "--bx", "64", "--by", "4", "--block-merge-x", "4", "--block-merge-y", "4", "--sn", "8", "--xcd-remap", "1"],
 }
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak (MI355X_MICROARCH.md: 8.0 TB/s spec)
 

@@ -79,6 +79,8 @@ MI355X options:
                         window: keep a rotating register window per resident plane.
 --temporal <0|1>        With --step n > 1: run the one-step stencil n times on chip (temporal blocking,
                         intermediate planes never leave the CU) instead of the fused stencil.
+--exact-y <0|1>         1 (default for single-stage kernels): the y halo rows of the source plane are fetched by the halo loader
+                        lanes, so every tile row is owned; 0: overlapped tiles (tile rows include the halo).
 --lazy-rims <0|1>       Read LDS rims when first needed (1) or when a plane arrives (0).
 --xcd-remap <0|1|2>     workgroup to tile mapping: 0 dispatch order, 1 contiguous chunk of tiles
                         per XCD, 2 one x-y band per XCD with all XCDs on the same stream block
@@ -134,6 +136,7 @@ inline GenResult generate(const std::vector<std::string> &args /* argv[1..] */) 
         else if (a == "--dtype") { if (!str_opt(o.dtype)) break; }
         else if (a == "--xrim") { if (!str_opt(o.xrim)) break; }
         else if (a == "--schedule") { if (!str_opt(o.schedule)) break; }
+        else if (a == "--exact-y") { if (!int_opt(o.exact_y, nullptr)) break; }
         else if (a == "--zgroup") { if (!int_opt(o.zgroup, nullptr)) break; }
         else if (a == "--temporal") { if (!int_opt(o.temporal, nullptr)) break; }
         else if (a == "--lazy-rims") { if (!int_opt(o.lazy_rims, nullptr)) break; }

@@ -120,7 +120,10 @@ inline KernelPlan make_plan(const Stencil &st, const GenOptions &o_in, const std
     p.TY = p.BY * p.RY;
     p.PADL = p.hxm ? round_up(p.hxm, vl) : 0;
     p.PADR = p.hxp ? round_up(p.hxp, vl) : 0;
-    p.oym = p.stages * p.hym; p.oyp = p.stages * p.hyp;
+    // The source plane's y halo rows are fetched by the halo loaders (like its x halo columns), so the
+    // first stage is valid on every tile row; each further on-chip stage loses hy rows per side.
+    p.exact_y = o.exact_y < 0 ? (p.stages == 1) : (o.exact_y != 0);
+    p.oym = (p.stages - (p.exact_y ? 1 : 0)) * p.hym; p.oyp = (p.stages - (p.exact_y ? 1 : 0)) * p.hyp;
     p.OY = p.has_y ? p.TY - p.oym - p.oyp : 1;
     if (p.OY < 1) { p.error = "tile has no rows left after the y halo"; return p; }
     if (p.PADL > p.TX || p.PADR > p.TX) { p.error = "x halo wider than the tile"; return p; }

@@ -79,35 +79,50 @@ def main():
         print("copy %d MiB: %.3f ms  %.0f GB/s (read+write)" % (nbytes >> 20, ms, 2 * nbytes / ms / 1e6), flush=True)
         out.write(json.dumps(dict(name="copy_%dMiB" % (nbytes >> 20), ms=ms, GBps=2 * nbytes / ms / 1e6)) + "\n")
         del a, b
-    for (name, ndim, d, dtype, args), k in kerns:
-        key = (tuple(d), dtype)
-        if key not in bufs:
-            bufs.clear()
-            torch.cuda.empty_cache()
-            tdt = torch.float32 if dtype == "fp32" else torch.float64
-            shape = tuple(d) if ndim == 3 else tuple(d[1:])
-            bufs[key] = (torch.rand(shape, dtype=tdt, device="cuda"), torch.zeros(shape, dtype=tdt, device="cuda"))
-        A, B = bufs[key]
-        if name.startswith("gold"):
-            for _ in range(2):
-                k.launch_gold(A.data_ptr(), B.data_ptr())
-            torch.cuda.synchronize()
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            for _ in range(4):
-                k.launch_gold(A.data_ptr(), B.data_ptr())
-            e1.record()
-            torch.cuda.synchronize()
-            n, ms = 4, e0.elapsed_time(e1)
-        else:
-            n, ms = k.run_timed(A.data_ptr(), B.data_ptr(), iterations=8 * k.info["step"], warmup=4, stream=torch.cuda.current_stream().cuda_stream)
-        dur = ms / n
-        gbs = k.bytes_per_launch() / dur / 1e6
-        gst = k.updates_per_launch() / dur / 1e6
-        rec = dict(name=name, dims=d, dtype=dtype, args=" ".join(args[:-1]), ms=dur, GBps=gbs, frac=gbs / 8000, GStencil=gst, lds=k.info["lds_bytes"], threads=k.info["threads"], grid=k.info["grid"])
-        out.write(json.dumps(rec) + "\n")
-        out.flush()
-        print("%-28s %8.3f ms %6.0f GB/s (%4.1f%%) %7.1f GSt  lds=%6d grid=%d" % (name, dur, gbs, gbs / 80, gst, k.info["lds_bytes"], k.info["grid"]), flush=True)
+    rounds = int(os.environ.get("EXPLORE_ROUNDS", "1"))
+    agg = {}
+    order_names = []
+    for rnd in range(rounds):
+      for (name, ndim, d, dtype, args), k in kerns:
+          key = (tuple(d), dtype)
+          if key not in bufs:
+              bufs.clear()
+              torch.cuda.empty_cache()
+              tdt = torch.float32 if dtype == "fp32" else torch.float64
+              shape = tuple(d) if ndim == 3 else tuple(d[1:])
+              bufs[key] = (torch.rand(shape, dtype=tdt, device="cuda"), torch.zeros(shape, dtype=tdt, device="cuda"))
+          A, B = bufs[key]
+          if name.startswith("gold"):
+              for _ in range(2):
+                  k.launch_gold(A.data_ptr(), B.data_ptr())
+              torch.cuda.synchronize()
+              e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+              e0.record()
+              for _ in range(4):
+                  k.launch_gold(A.data_ptr(), B.data_ptr())
+              e1.record()
+              torch.cuda.synchronize()
+              n, ms = 4, e0.elapsed_time(e1)
+          else:
+              n, ms = k.run_timed(A.data_ptr(), B.data_ptr(), iterations=8 * k.info["step"], warmup=4, stream=torch.cuda.current_stream().cuda_stream)
+          dur = ms / n
+          gbs = k.bytes_per_launch() / dur / 1e6
+          gst = k.updates_per_launch() / dur / 1e6
+          rec = dict(name=name, dims=d, dtype=dtype, args=" ".join(args[:-1]), ms=dur, GBps=gbs, frac=gbs / 8000, GStencil=gst, lds=k.info["lds_bytes"], threads=k.info["threads"], grid=k.info["grid"])
+          out.write(json.dumps(rec) + "\n")
+          out.flush()
+          if rounds == 1:
+              print("%-28s %8.3f ms %6.0f GB/s (%4.1f%%) %7.1f GSt  lds=%6d grid=%d" % (name, dur, gbs, gbs / 80, gst, k.info["lds_bytes"], k.info["grid"]), flush=True)
+          if name not in agg:
+              order_names.append(name)
+          agg.setdefault(name, []).append((dur, gbs, gst))
+    if rounds > 1:
+        import statistics
+        print("median of %d interleaved rounds:" % rounds)
+        for name in order_names:
+            v = agg[name]
+            dur = statistics.median(x[0] for x in v); gbs = statistics.median(x[1] for x in v); gst = statistics.median(x[2] for x in v)
+            print("%-28s %8.3f ms %6.0f GB/s (%4.1f%%) %7.1f GSt   [min %.3f max %.3f ms]" % (name, dur, gbs, gbs / 80, gst, min(x[0] for x in v), max(x[0] for x in v)), flush=True)
 
 
 if __name__ == "__main__":
