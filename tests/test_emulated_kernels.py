@@ -80,3 +80,43 @@ def test_emulated_variants_bit_exact(vid, ndim, pts, dims, opts, tmp_path):
     A3 = oracle.fill_random(spec.shape, dt); B3 = np.zeros_like(A3)
     run_emulated(lib, A3, B3, spec.iterations, step, gold=True)
     assert np.array_equal(A3, A2) and np.array_equal(B3, B2)
+
+
+EDGE = [
+    ("3d_min_interior", 3, "STAR3", (3, 3, 3), ["--3d", "--dtype", "fp64"]),
+    ("3d_thin", 3, "STAR3", (5, 4, 7), ["--3d", "--dtype", "fp32", "--sn", "1"]),
+    ("3d_one_tile_row", 3, "STAR3", (6, 3, 260), ["--3d", "--dtype", "fp32", "--sn", "3", "--prefetch"]),
+    ("3d_step2_min", 3, "STAR3", (5, 5, 5), ["--3d", "--dtype", "fp64", "--step", "2"]),
+    ("3d_temporal2_min", 3, "STAR3", (5, 5, 6), ["--3d", "--dtype", "fp64", "--step", "2", "--temporal", "1", "--by", "4", "--block-merge-y", "2"]),
+    ("3d_temporal3_ragged", 3, "STAR3", (13, 17, 70), ["--3d", "--dtype", "fp64", "--step", "3", "--temporal", "1", "--bx", "18", "--by", "8", "--block-merge-y", "2", "--sn", "2", "--prefetch"]),
+    ("2d_min_interior", 2, "STAR2", (1, 3, 3), ["--dtype", "fp64"]),
+    ("2d_box25_min", 2, "BOX25", (1, 5, 5), ["--dtype", "fp32"]),
+    ("2d_stream_min", 2, "STAR2", (1, 3, 9), ["--dtype", "fp32", "--streaming", "--sn", "1"]),
+    ("2d_temporal2_tile_small", 2, "BOX9", (1, 7, 9), ["--dtype", "fp64", "--step", "2", "--temporal", "1"]),
+    ("2d_oddN_box25_stream", 2, "BOX25", (1, 23, 31), ["--dtype", "fp64", "--streaming", "--sn", "4", "--xrim", "lds"]),
+]
+
+
+@pytest.mark.parametrize("vid,ndim,pts,dims,opts", EDGE, ids=[v[0] for v in EDGE])
+def test_emulated_edge_geometries(vid, ndim, pts, dims, opts, tmp_path):
+    """Grids barely larger than the halo, grids smaller than a tile, single-plane stream blocks."""
+    mg = _mg()
+    stc = str(tmp_path / "e.stc")
+    write_stc(stc, ndim, dims, 4, getattr(mg, pts))
+    step = int(opts[opts.index("--step") + 1]) if "--step" in opts else 1
+    lib = build_emulated(tmp_path, stc, opts)
+    spec = oracle.Spec(stc, ndim, step)
+    dt = np.float32 if "fp32" in opts else np.float64
+    A = oracle.fill_random(spec.shape, dt); B = np.zeros_like(A)
+    A2, B2 = A.copy(), B.copy()
+    oracle.run(spec, A2, B2, contract=1)
+    n = run_emulated(lib, A, B, spec.iterations, step)
+    assert n == spec.launches
+    if "--temporal" in opts:
+        assert oracle.check(spec, A, A2)["max_rel"] < 1e-12 and oracle.check(spec, B, B2)["max_rel"] < 1e-12
+        h = spec.halo
+        ring = np.ones(A.shape, bool)
+        ring[tuple(slice(h, s - h) for s in A.shape)] = False
+        assert np.array_equal(A[ring], A2[ring]) and np.array_equal(B[ring], B2[ring])
+    else:
+        assert np.array_equal(A, A2) and np.array_equal(B, B2)
