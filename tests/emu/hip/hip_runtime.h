@@ -72,9 +72,13 @@ inline void run_block(dim3 block, std::function<void()> fn) {
         f.ctx.uc_link = &sched_ctx;
         makecontext(&f.ctx, (void (*)())trampoline, 0);
     }
+    // EMU_ORDER=reverse runs the fibers of every phase last-to-first: a missing barrier between a
+    // writer and a reader shows up under at least one of the two orders
+    static const bool reverse = getenv("EMU_ORDER") && strcmp(getenv("EMU_ORDER"), "reverse") == 0;
     for (;;) {
         bool any = false;
-        for (unsigned t = 0; t < nt; t++) {
+        for (unsigned i = 0; i < nt; i++) {
+            const unsigned t = reverse ? nt - 1 - i : i;
             Fiber &f = fibers[t];
             if (f.done) continue;
             any = true;

@@ -120,3 +120,32 @@ def test_emulated_edge_geometries(vid, ndim, pts, dims, opts, tmp_path):
         assert np.array_equal(A[ring], A2[ring]) and np.array_equal(B[ring], B2[ring])
     else:
         assert np.array_equal(A, A2) and np.array_equal(B, B2)
+
+
+RACE = [
+    ("3d_temporal2_prefetch", 3, "STAR3", (17, 21, 300), ["--3d", "--dtype", "fp64", "--sn", "6", "--step", "2", "--temporal", "1", "--prefetch", "--by", "8", "--block-merge-y", "2"]),
+    ("3d_temporal3_lds", 3, "STAR3", (15, 19, 140), ["--3d", "--dtype", "fp64", "--sn", "4", "--step", "3", "--temporal", "1", "--xrim", "lds", "--bx", "34", "--by", "8", "--block-merge-y", "2"]),
+    ("3d_step1_window_lazy", 3, "STAR3", (15, 19, 300), ["--3d", "--dtype", "fp64", "--sn", "5", "--schedule", "window", "--lazy-rims", "1", "--xrim", "lds"]),
+    ("3d_step1_scatter_prefetch", 3, "STAR3", (15, 19, 300), ["--3d", "--dtype", "fp64", "--sn", "5", "--prefetch", "--xrim", "lds"]),
+    ("2d_stream_temporal4", 2, "STAR2", (1, 40, 270), ["--dtype", "fp64", "--streaming", "--sn", "7", "--step", "4", "--temporal", "1", "--xrim", "lds"]),
+    ("2d_tile_temporal3", 2, "BOX9", (1, 40, 140), ["--dtype", "fp64", "--step", "3", "--temporal", "1", "--xrim", "lds"]),
+]
+
+
+@pytest.mark.parametrize("vid,ndim,pts,dims,opts", RACE, ids=[v[0] for v in RACE])
+def test_emulated_reverse_fiber_order(vid, ndim, pts, dims, opts, tmp_path, monkeypatch):
+    """LDS hand-off hazards: run the same kernels with the fibers of every barrier phase executed
+    last-to-first (tests/emu EMU_ORDER=reverse); together with the forward order this exposes any
+    writer/reader pair that lacks a barrier."""
+    monkeypatch.setenv("EMU_ORDER", "reverse")
+    mg = _mg()
+    stc = str(tmp_path / "r.stc")
+    write_stc(stc, ndim, dims, 4, getattr(mg, pts))
+    step = int(opts[opts.index("--step") + 1]) if "--step" in opts else 1
+    lib = build_emulated(tmp_path, stc, opts)
+    spec = oracle.Spec(stc, ndim, step)
+    A = oracle.fill_random(spec.shape, np.float64); B = np.zeros_like(A)
+    A2, B2 = A.copy(), B.copy()
+    oracle.run(spec, A2, B2, contract=1)
+    run_emulated(lib, A, B, spec.iterations, step)
+    assert oracle.check(spec, A, A2)["max_rel"] < 1e-12 and oracle.check(spec, B, B2)["max_rel"] < 1e-12
