@@ -19,8 +19,10 @@
 //   --prefetch          software prefetch of the next plane into VGPRs across the barrier
 //   --dist/--merge-forward  accepted and validated like the reference (they select the
 //                       forward/backward partition reported as Range/Dist); the CDNA4
-//                       schedule keeps every partial sum in registers so they do not
-//                       change the emitted arithmetic
+//                       "scatter" schedule is that data-reuse idea with every partial sum
+//                       carried in registers, so they do not change the emitted arithmetic
+//   --step n            fused stencil (exact reference arithmetic) or, with --temporal 1,
+//                       n on-chip applications of the one-step stencil (temporal blocking)
 #pragma once
 #include <string>
 #include <vector>
@@ -61,9 +63,9 @@ struct GenOptions {
     int halo_spread = 0;         // spread the halo loader tasks over all wavefronts of the workgroup (no gain measured)
     int xedge_select = 0;        // --xrim dpp: wavefront-edge lanes take the LDS value by select instead of a branch
     int zgroup = 4;              // --xcd-remap 3: stream blocks of one tile taken by consecutive workgroups
+    int prefetch_auto = 1;       // temporal pipelines prefetch unless --prefetch-auto 0 (+28 % measured)
     int temporal = 0;            // step > 1: apply the one-step stencil `step` times on chip instead of the fused stencil
     std::string schedule = "scatter";  // scatter: partial sums carried in VGPRs; window: rotating register windows
-    int tile_order = 0;          // 0: x fastest, then y, then stream blocks; 1: stream blocks fastest last->first
 };
 
 struct Tap {

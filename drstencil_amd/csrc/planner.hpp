@@ -43,7 +43,7 @@ inline KernelPlan make_plan(const Stencil &st, const GenOptions &o_in, const std
     p.fp32 = (o.dtype == "fp32");
     p.L = st.L; p.M = st.M; p.N = st.N;
     p.iterations = st.iterations; p.step = st.step; p.halo = st.halo; p.dist = st.dist; p.range = st.range();
-    p.prefetch = o.prefetch;
+    p.prefetch = o.prefetch || (o.temporal && o_in.step > 1 && !o.ref_defaults && o.prefetch_auto);
 
     const bool stream2d = (st.ndim == 2 && o.streaming);
     p.has_s = (st.ndim == 3) || stream2d;
@@ -52,6 +52,30 @@ inline KernelPlan make_plan(const Stencil &st, const GenOptions &o_in, const std
     // MI355X defaults for whatever geometry the user left unset: one wavefront (64
     // lanes) along x with 16-byte accesses per lane.
     const int vec_elems = p.fp32 ? 4 : 2;
+    // Temporal pipelines (tuned on 3d7pt_star 1024^3, profiles/r01_tune_c4_s2.txt): pick the lane count
+    // whose OWNED width (mx*bx - 2*roundup((step-1)*hx, mx)) tiles N with the least idle lanes -- e.g.
+    // 66 lanes x 4 = 264 columns own 256, so 4 tiles cover N = 1024 where 64 lanes would need 5 --
+    // many short rows per workgroup (15 x 2), 32-plane stream blocks, software prefetch, dispatch order.
+    if (!o.ref_defaults && o.temporal && st.step > 1 && st.ndim == 3) {
+        int hx = 0;
+        for (auto &e : st.base.v) hx = std::max(hx, std::abs(e.first.i));
+        if (!o.mx_set) { o.bmx = vec_elems; o.cmx = 1; o.mx_set = true; }
+        const int mxv = std::max(o.bmx, o.cmx);
+        if (!o.bx_set) {
+            const int al = round_up((st.step - 1) * hx, mxv);
+            long best = -1;
+            for (int bx : {66, 64, 34, 32}) {   // wider rows leave too few rows per workgroup (measured slower)
+                const int ox = bx * mxv - 2 * al;
+                if (ox < 1) continue;
+                const long cost = (long)ceil_div(st.N - st.halo, ox) * bx * mxv;   // lane-columns spent on a row
+                if (best < 0 || cost < best) { best = cost; o.bx = bx; }
+            }
+            o.bx_set = true;
+        }
+        if (!o.by_set) { o.by = std::max(1, std::min(15, 1000 / o.bx)); o.by_set = true; }
+        if (!o.my_set) { o.bmy = 2; o.cmy = 1; o.my_set = true; }
+        if (!o.sn_set) { o.sn = 32; o.sn_set = true; }
+    }
     if (!o.ref_defaults) {
         if (!o.bx_set) o.bx = 64;
         if (!o.mx_set) { o.bmx = vec_elems; o.cmx = 1; }
