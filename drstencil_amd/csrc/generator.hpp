@@ -81,6 +81,8 @@ MI355X options:
                         intermediate planes never leave the CU) instead of the fused stencil.
 --exact-y <0|1>         1 (default for single-stage kernels): the y halo rows of the source plane are fetched by the halo loader
                         lanes, so every tile row is owned; 0: overlapped tiles (tile rows include the halo).
+--clamp-loads <0|1>     1 (default): branch-free loads -- lanes outside the grid read the plane origin (their
+                        values never reach a stored output); 0: loads under per-lane guards.
 --halo-spread <0|1>     Spread the halo loader tasks over all wavefronts (default 0: the first lanes take them).
 --xedge-select <0|1>    With --xrim dpp: wavefront-edge lanes pick the LDS value by select (1) or branch (0, default).
 --lazy-rims <0|1>       Read LDS rims when first needed (1) or when a plane arrives (0).
@@ -140,6 +142,7 @@ inline GenResult generate(const std::vector<std::string> &args /* argv[1..] */) 
         else if (a == "--schedule") { if (!str_opt(o.schedule)) break; }
         else if (a == "--exact-y") { if (!int_opt(o.exact_y, nullptr)) break; }
         else if (a == "--xedge-select") { if (!int_opt(o.xedge_select, nullptr)) break; }
+        else if (a == "--clamp-loads") { if (!int_opt(o.clamp_loads, nullptr)) break; }
         else if (a == "--halo-spread") { if (!int_opt(o.halo_spread, nullptr)) break; }
         else if (a == "--zgroup") { if (!int_opt(o.zgroup, nullptr)) break; }
         else if (a == "--prefetch-auto") { if (!int_opt(o.prefetch_auto, nullptr)) break; }
