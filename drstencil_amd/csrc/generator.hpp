@@ -142,6 +142,7 @@ inline GenResult generate(const std::vector<std::string> &args /* argv[1..] */) 
         else if (a == "--schedule") { if (!str_opt(o.schedule)) break; }
         else if (a == "--exact-y") { if (!int_opt(o.exact_y, nullptr)) break; }
         else if (a == "--xedge-select") { if (!int_opt(o.xedge_select, nullptr)) break; }
+        else if (a == "--debug-drop-barrier") { if (!int_opt(o.debug_drop_barrier, nullptr)) break; }
         else if (a == "--clamp-loads") { if (!int_opt(o.clamp_loads, nullptr)) break; }
         else if (a == "--halo-spread") { if (!int_opt(o.halo_spread, nullptr)) break; }
         else if (a == "--zgroup") { if (!int_opt(o.zgroup, nullptr)) break; }
