@@ -112,11 +112,12 @@ def cpu_baseline(workload, step, budget_s=15.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="c4", choices=sorted(WORKLOADS))
     ap.add_argument("--kernel-args", default=None, help="override the generator options (space separated)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--headline-only", action="store_true", help="skip the side measurements (profiling runs: one dr_ kernel in the trace)")
     args = ap.parse_args()
 
     import torch
@@ -135,7 +136,7 @@ def main():
     kern1 = kernf = None
     if world == 1:
         kern = drs.Kernel(opts + [w["stc"]])
-        if args.workload in STEP1 and not args.kernel_args:
+        if args.workload in STEP1 and not args.kernel_args and not args.headline_only:
             kern1 = drs.Kernel(STEP1[args.workload] + [w["stc"]])
             kernf = drs.Kernel(FUSED2[args.workload] + [w["stc"]])
     else:
