@@ -21,6 +21,15 @@ def golden_dir():
     return GOLDEN
 
 
+def _build_kernel(args):
+    import drstencil_amd as drs
+    try:
+        drs.Kernel(args)
+        return None
+    except Exception as e:
+        return "%s: %s" % (" ".join(args), str(e)[-300:])
+
+
 def pytest_sessionstart(session):
     """GPU sessions: make sure every kernel the gpu tests use is built (normally a cache hit:
     __graft_entry__.build() prebuilds them) BEFORE anything initialises HIP -- a process that
@@ -29,7 +38,11 @@ def pytest_sessionstart(session):
     if "gpu" not in markexpr or "not gpu" in markexpr:
         return
     sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import subprocess
     import drstencil_amd as drs
+    if not os.path.exists(drs.LIB_PATH) or not os.path.exists(drs.CLI_PATH):
+        # a checkout without built artefacts: build the host code first (g++, seconds)
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "drstencil_amd", "csrc")], stdout=subprocess.DEVNULL)
     from gpu_cases import all_build_args, golden_args
     from helpers import golden_cases, load_golden
     jobs = all_build_args()
@@ -40,8 +53,12 @@ def pytest_sessionstart(session):
     from gpu_cases import stc as stcp
     jobs.append(["--dtype", "fp32", "--streaming", "--xrim", "lds", stcp("t2_box25")])
     jobs.append(["--dtype", "fp32", "--streaming", "--xrim", "dpp", stcp("t2_box25")])
-    for j in jobs:
-        drs.Kernel(j)
+    # cache hits return at once; misses are compiled in parallel worker processes (hipcc), all of it
+    # before this process initialises HIP
+    from concurrent.futures import ProcessPoolExecutor
+    with ProcessPoolExecutor(max_workers=min(16, os.cpu_count() or 1)) as ex:
+        bad = [r for r in ex.map(_build_kernel, jobs) if r]
+    assert not bad, "kernel builds failed:\n" + "\n".join(bad)
     # slab-view kernels of test_slab_decomposition_on_one_gpu (compiled here, before HIP is up)
     import tempfile
     from drstencil_amd.multigpu import HipSweep, SlabPlan
