@@ -80,8 +80,12 @@ FULL = [
 ]
 
 
+# BASELINE config C1: 2d5pt_star 4096^2 fp32, 100 iterations (the reference-CPU-path config): HIP vs oracle at full size
+C1 = ("C1_2d5pt_4096_fp32_it100", 2, os.path.join(CFG, "c1_2d5pt_star_4096.stc"), ["--dtype", "fp32"])
+
+
 def all_build_args():
-    out = [c[3] + [c[2]] for c in SMALL] + [SMOKE[3] + [SMOKE[2]]] + [c[3] + [c[2]] for c in FULL]
+    out = [c[3] + [c[2]] for c in SMALL] + [SMOKE[3] + [SMOKE[2]]] + [c[3] + [c[2]] for c in FULL] + [C1[3] + [C1[2]]]
     return out
 
 

@@ -170,6 +170,31 @@ def test_full_size_properties(torch_cuda, cid, ndim, stc, opts):
         assert np.array_equal(got, dst[h:nsl - h]), cid
 
 
+def test_c1_full_size_100_iterations_vs_oracle(torch_cuda):
+    """BASELINE config C1 (2d5pt_star 4096^2 fp32, 100 iterations = 100 launches): the HIP path against
+    the CPU oracle at full size, bit for bit (the run SURVEY section 7 flags as the tight one for fp32)."""
+    import drstencil_amd as drs
+    from gpu_cases import C1
+    torch = torch_cuda
+    cid, ndim, stc, opts = C1
+    kern = drs.Kernel(opts + [stc])
+    spec = oracle.Spec(stc, ndim, 1)
+    assert spec.iterations == 100 and spec.launches == 100
+    A0 = oracle.fill_random(spec.shape, np.float32)
+    assert A0.flat[0] == np.float32(0.84018771754595234)
+    A_ref, B_ref = A0.copy(), np.zeros_like(A0)
+    assert oracle.run(spec, A_ref, B_ref, contract=1) == 100
+    n, A, B = run_hip(torch, kern, A0, np.zeros_like(A0))
+    assert n == 100
+    m = oracle.check(spec, A, A_ref)
+    assert m["max_rel"] <= 1e-6, m
+    assert np.array_equal(A, A_ref) and np.array_equal(B, B_ref)
+    # against uncontracted (g++ -O0 style) fp32 arithmetic the two roundings drift ~1e-8 per sweep
+    A_nc, B_nc = A0.copy(), np.zeros_like(A0)
+    oracle.run(spec, A_nc, B_nc, contract=0)
+    assert oracle.check(spec, A, A_nc)["max_rel"] <= 2e-6
+
+
 def test_dpp_wave_shift_semantics(torch_cuda):
     """--xrim dpp relies on wave_shr:1 / wave_shl:1 moving data by one lane across the whole
     64-lane wavefront on gfx950: a dpp kernel and an lds kernel must agree bit for bit."""

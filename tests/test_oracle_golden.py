@@ -106,3 +106,24 @@ def test_check_error_metric_matches_definition(tmp_path):
     assert m["rms"] == pytest.approx(np.sqrt(1e-6 / n_int), rel=1e-9)
     m0 = oracle.check(spec, a_ref, a_ref)
     assert m0["max_abs"] == 1e-13 and m0["rms"] == 0.0   # the reference's 1e-13 floor
+
+
+def test_c1_reference_cpu_path_plumbing():
+    """BASELINE config C1: 2d5pt_star 4096^2 fp32, 100 iterations on the CPU path (plumbing + correctness):
+    launch count, frozen rings of both buffers, contraction modes within the fp32 bar of each other."""
+    import os
+    stc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "benchmarks", "configs", "c1_2d5pt_star_4096.stc")
+    spec = oracle.Spec(stc, 2, 1)
+    assert spec.shape == (4096, 4096) and spec.iterations == 100 and spec.halo == 1
+    A0 = oracle.fill_random(spec.shape, np.float32)
+    A, B = A0.copy(), np.zeros_like(A0)
+    assert oracle.run(spec, A, B, contract=1) == 100
+    assert np.isfinite(A).all()
+    assert np.array_equal(A[0], A0[0]) and np.array_equal(A[-1], A0[-1]) and np.array_equal(A[:, 0], A0[:, 0]) and np.array_equal(A[:, -1], A0[:, -1])
+    assert not B[0].any() and not B[-1].any() and not B[:, 0].any() and not B[:, -1].any()
+    # FMA-contracted vs uncontracted fp32 arithmetic drift apart by ~1e-8 per sweep: 1.1e-6 after 100
+    # sweeps (SURVEY section 7: the 1e-6 gate only makes sense against an oracle with the SAME
+    # arithmetic as the kernel -- the HIP kernels are compared with contract=1, bit for bit)
+    A2, B2 = A0.copy(), np.zeros_like(A0)
+    oracle.run(spec, A2, B2, contract=0)
+    assert oracle.check(spec, A, A2)["max_rel"] <= 2e-6
