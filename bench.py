@@ -31,33 +31,36 @@ WORKLOADS = {
     "c2": dict(stc=os.path.join(CFG, "c2_2d5pt_star_8192.stc"), ndim=2, dtype="fp32", name="2d5pt_star 8192^2 fp32 (BASELINE C2), iterations 4"),
     "c5": dict(stc=os.path.join(CFG, "c5_2d25pt_box_16384.stc"), ndim=2, dtype="fp64", name="2d25pt_box 16384^2 fp64 (BASELINE C5), iterations 4"),
 }
-# tuned generator options per workload (see profiles/ and DESIGN.md; found with drstencil_amd/tuner)
+# tuned generator options per workload (found with drstencil_amd/tuner; logs under profiles/).
+# Headline for the 3D workloads: two time steps per launch with the reference's own --step 2 arithmetic
+# (algebraically fused 25-point stencil, one pass) -- bit-identical to the oracle.  One wavefront (64 lanes x
+# 4 points) per row, 8 lane rows x 2 rows (16 x 256 tile, halo fetched by the halo loader lanes), 32-plane
+# stream blocks, software prefetch, one x-y band per XCD.  The exhaustive 1780-configuration search
+# (profiles/r01_tune_c4_s2_exhaustive.txt) puts the 32x16-lane and 64x8-lane fused kernels and the 66x15-lane
+# temporal pipeline within a few per cent of each other; their order changes from device to device.
 TUNED = {
-    # 2 time steps per launch on chip (temporal blocking); 66 lanes x 4 points = 264 columns, 256 owned:
-    # 4 tiles cover N = 1024 exactly; 15 x 2 = 30 rows, 26 owned
-    "c4": ["--3d", "--dtype", "fp32", "--step", "2", "--temporal", "1", "--prefetch", "--bx", "66", "--by", "15",
-           "--block-merge-x", "4", "--block-merge-y", "2", "--sn", "32", "--xcd-remap", "0"],
-    "c3": ["--3d", "--dtype", "fp32", "--step", "2", "--temporal", "1", "--prefetch", "--bx", "66", "--by", "15",
-           "--block-merge-x", "4", "--block-merge-y", "2", "--sn", "16", "--xcd-remap", "0"],
+    "c4": ["--3d", "--dtype", "fp32", "--step", "2", "--prefetch", "--bx", "64", "--by", "8", "--block-merge-x", "4", "--block-merge-y", "2", "--sn", "32", "--xcd-remap", "2"],
+    "c3": ["--3d", "--dtype", "fp32", "--step", "2", "--prefetch", "--bx", "32", "--by", "8", "--block-merge-x", "4", "--block-merge-y", "2", "--sn", "32", "--xcd-remap", "2"],
     "c2": ["--dtype", "fp32", "--bx", "64", "--by", "4", "--block-merge-x", "4", "--block-merge-y", "8", "--xcd-remap", "0"],
     "c5": ["--dtype", "fp64", "--bx", "64", "--by", "4", "--block-merge-x", "2", "--block-merge-y", "8", "--xcd-remap", "0", "--clamp-loads", "0"],
 }
-# the same workloads without temporal blocking (one time step per launch): highest roofline fraction
+# the same workloads with one time step per launch: highest roofline fraction
 STEP1 = {
     "c4": ["--3d", "--dtype", "fp32", "--bx", "64", "--by", "4", "--block-merge-x", "4", "--block-merge-y", "4", "--sn", "8", "--xcd-remap", "2"],
     "c3": ["--3d", "--dtype", "fp32", "--bx", "64", "--by", "4", "--block-merge-x", "4", "--block-merge-y", "4", "--sn", "8", "--xcd-remap", "1"],
 }
-# the reference's own --step 2 semantics (algebraically fused 25-point stencil, one pass): bit-identical to the oracle
-FUSED2 = {
-    "c4": ["--3d", "--dtype", "fp32", "--step", "2", "--prefetch", "--bx", "64", "--by", "8", "--block-merge-x", "4", "--block-merge-y", "2", "--sn", "24", "--xcd-remap", "2"],
-    "c3": ["--3d", "--dtype", "fp32", "--step", "2", "--prefetch", "--bx", "32", "--by", "8", "--block-merge-x", "4", "--block-merge-y", "2", "--sn", "32", "--xcd-remap", "2"],
+# on-chip temporal blocking (two applications of the one-step stencil per launch; equal to the fused stencil up to
+# rounding, 6.8e-7 relative at full size): 66 lanes x 4 = 264 columns own 256, so 4 tiles cover N = 1024 exactly
+TEMPORAL2 = {
+    "c4": ["--3d", "--dtype", "fp32", "--step", "2", "--temporal", "1", "--prefetch", "--bx", "66", "--by", "15", "--block-merge-x", "4", "--block-merge-y", "2", "--sn", "32", "--xcd-remap", "0"],
+    "c3": ["--3d", "--dtype", "fp32", "--step", "2", "--temporal", "1", "--prefetch", "--bx", "66", "--by", "15", "--block-merge-x", "4", "--block-merge-y", "2", "--sn", "16", "--xcd-remap", "0"],
 }
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak (MI355X_MICROARCH.md: 8.0 TB/s spec)
 
 
 def kernel_arg_sets():
     """Kernels bench.py needs; prebuilt by __graft_entry__.build()."""
-    return [TUNED[w] + [WORKLOADS[w]["stc"]] for w in ("c4", "c3", "c2", "c5")] + [STEP1[w] + [WORKLOADS[w]["stc"]] for w in ("c4", "c3")] + [FUSED2[w] + [WORKLOADS[w]["stc"]] for w in ("c4", "c3")]
+    return [TUNED[w] + [WORKLOADS[w]["stc"]] for w in ("c4", "c3", "c2", "c5")] + [STEP1[w] + [WORKLOADS[w]["stc"]] for w in ("c4", "c3")] + [TEMPORAL2[w] + [WORKLOADS[w]["stc"]] for w in ("c4", "c3")]
 
 
 def pmc_traffic(option_string):
@@ -138,7 +141,7 @@ def main():
         kern = drs.Kernel(opts + [w["stc"]])
         if args.workload in STEP1 and not args.kernel_args and not args.headline_only:
             kern1 = drs.Kernel(STEP1[args.workload] + [w["stc"]])
-            kernf = drs.Kernel(FUSED2[args.workload] + [w["stc"]])
+            kernf = drs.Kernel(TEMPORAL2[args.workload] + [w["stc"]])
     else:
         from drstencil_amd.multigpu import HipSweep, SlabPlan, SlabRun
         sweep = HipSweep(w["stc"], opts, os.path.join(ROOT, "drstencil_amd", "_kcache"))
@@ -195,7 +198,7 @@ def main():
                     "avg_launch_ms": ms1 / n1, "achieved_GBps": by * n1 / (ms1 * 1e-3) / 1e9,
                     "roofline_frac": by * n1 / (ms1 * 1e-3) / 1e9 / HBM_PEAK_GBS}
         step1 = side(kern1, STEP1[args.workload], 16) if kern1 is not None else None
-        fused2 = side(kernf, FUSED2[args.workload], 32) if kernf is not None else None
+        fused2 = side(kernf, TEMPORAL2[args.workload], 32) if kernf is not None else None
     else:
         run = SlabRun(torch, dist, (L, M, N) if w["ndim"] == 3 else (M, N), H, step, iters, rank, world, sweep, dev, tdt)
         g = torch.Generator(device=dev).manual_seed(1 + rank)
@@ -246,7 +249,7 @@ def main():
                          "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": avg_launch_s * 1e3},
         }
         out["step1_kernel"] = step1                 # one time step per launch: highest roofline fraction
-        out["fused_step2_kernel"] = fused2          # reference --step 2 arithmetic in one pass: bit-exact vs the oracle
+        out["temporal_step2_kernel"] = fused2       # on-chip temporal blocking (2 stages): equal to the headline up to rounding
         if not args.no_cpu_baseline and world == 1:
             sys.path.insert(0, ROOT)
             out["cpu_baseline"] = cpu_baseline(args.workload, step)
