@@ -110,9 +110,12 @@ class Spec:
         self.ndim, self.step = ndim, step
 
     def close(self):
-        if self.h:
-            lib().drs_spec_close(self.h)
-            self.h = None
+        try:
+            if getattr(self, "h", None):
+                lib().drs_spec_close(self.h)
+                self.h = None
+        except Exception:   # interpreter shutdown
+            pass
 
     __del__ = close
 
@@ -214,9 +217,12 @@ class Kernel:
         return 2 * (4 if i["dtype"] == "fp32" else 8) * pts
 
     def close(self):
-        if getattr(self, "h", None):
-            lib().drs_kernel_close(self.h)
-            self.h = None
+        try:
+            if getattr(self, "h", None):
+                lib().drs_kernel_close(self.h)
+                self.h = None
+        except Exception:   # interpreter shutdown
+            pass
 
     __del__ = close
 

@@ -134,6 +134,13 @@ static unsigned long long fnv1a(const std::string &s) {
     return h;
 }
 
+// single-quote a path for the shell
+static std::string shq(const std::string &s) {
+    std::string o = "'";
+    for (char c : s) { if (c == '\'') o += "'\\''"; else o += c; }
+    return o + "'";
+}
+
 static bool file_exists(const std::string &p) { struct stat sb; return stat(p.c_str(), &sb) == 0 && sb.st_size > 0; }
 
 static std::string run_capture(const std::string &cmd, int *rc) {
@@ -173,7 +180,7 @@ drs_kernel *drs_kernel_build(int argc, const char *const *argv, const char *cach
         const std::string tsrc = src + tmpl + ".hip", tso = so + tmpl;
         if (!write_text(tsrc, r.source)) { if (log) *log = dup_cstr("cannot write " + tsrc + "\n"); return nullptr; }
         int rc = 0;
-        std::string out = run_capture(hipcc + " " + flags + " -I" + support + " -o " + tso + " " + tsrc, &rc);
+        std::string out = run_capture(shq(hipcc) + " " + flags + " -I" + shq(support) + " -o " + shq(tso) + " " + shq(tsrc), &rc);
         if (rc != 0 || !file_exists(tso)) {
             if (log) *log = dup_cstr("hipcc failed (" + std::to_string(rc) + "):\n" + out);
             unlink(tso.c_str());

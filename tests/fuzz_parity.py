@@ -4,7 +4,7 @@ or fused, odd lane counts, both dtypes) on small ragged grids, each compared wit
 bit for bit for single-pass kernels, within the dtype's bar for temporal pipelines.
 Builds everything before HIP is initialised."""
 import os, random, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))   # tests/ may use the oracle as the checker
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
 import drstencil_amd as drs
