@@ -65,7 +65,7 @@ struct GenOptions {
     int halo_spread = 0;         // spread the halo loader tasks over all wavefronts of the workgroup (no gain measured)
     int xedge_select = 0;        // --xrim dpp: wavefront-edge lanes take the LDS value by select instead of a branch
     int zgroup = 4;              // --xcd-remap 3: stream blocks of one tile taken by consecutive workgroups
-    int prefetch_auto = 1;       // temporal pipelines prefetch unless --prefetch-auto 0 (+28 % measured)
+    int prefetch_auto = 1;       // 3D kernels with step > 1 (fused or temporal) prefetch unless --prefetch-auto 0 (+28 % measured)
     int temporal = 0;            // step > 1: apply the one-step stencil `step` times on chip instead of the fused stencil
     std::string schedule = "scatter";  // scatter: partial sums carried in VGPRs; window: rotating register windows
 };

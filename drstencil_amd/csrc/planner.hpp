@@ -43,7 +43,7 @@ inline KernelPlan make_plan(const Stencil &st, const GenOptions &o_in, const std
     p.fp32 = (o.dtype == "fp32");
     p.L = st.L; p.M = st.M; p.N = st.N;
     p.iterations = st.iterations; p.step = st.step; p.halo = st.halo; p.dist = st.dist; p.range = st.range();
-    p.prefetch = o.prefetch || (o.temporal && o_in.step > 1 && !o.ref_defaults && o.prefetch_auto);
+    p.prefetch = o.prefetch || (o_in.step > 1 && st.ndim == 3 && !o.ref_defaults && o.prefetch_auto);
 
     const bool stream2d = (st.ndim == 2 && o.streaming);
     p.has_s = (st.ndim == 3) || stream2d;
@@ -73,6 +73,14 @@ inline KernelPlan make_plan(const Stencil &st, const GenOptions &o_in, const std
             o.bx_set = true;
         }
         if (!o.by_set) { o.by = std::max(1, std::min(15, 1000 / o.bx)); o.by_set = true; }
+        if (!o.my_set) { o.bmy = 2; o.cmy = 1; o.my_set = true; }
+        if (!o.sn_set) { o.sn = 32; o.sn_set = true; }
+    }
+    // Fused multi-step kernels in 3D (step > 1 without --temporal; tuned on 3d7pt_star 1024^3 step 2,
+    // profiles/r01_tune_c4_s2_exhaustive.txt): the wide fused window costs registers, so 2 rows per lane on
+    // 8 lane rows, longer stream blocks (the z halo is step*order planes) and software prefetch.
+    if (!o.ref_defaults && !o.temporal && st.step > 1 && st.ndim == 3) {
+        if (!o.by_set) { o.by = 8; o.by_set = true; }
         if (!o.my_set) { o.bmy = 2; o.cmy = 1; o.my_set = true; }
         if (!o.sn_set) { o.sn = 32; o.sn_set = true; }
     }
