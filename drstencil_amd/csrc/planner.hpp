@@ -84,6 +84,19 @@ inline KernelPlan make_plan(const Stencil &st, const GenOptions &o_in, const std
         if (!o.my_set) { o.bmy = 2; o.cmy = 1; o.my_set = true; }
         if (!o.sn_set) { o.sn = 32; o.sn_set = true; }
     }
+    // One-step 3D kernels (tuned by the exhaustive search on 3d7pt_star 1024^3, profiles/r01_tune_c4_s1_exhaustive.txt:
+    // 80 % of the HBM peak = the chip's copy ceiling): a workgroup of 512 lanes owns FULL rows when a row fits
+    // 256 lanes (no x halo, every plane access is a run of whole rows), 4 rows per lane, 4-plane stream blocks,
+    // software prefetch.
+    if (!o.ref_defaults && st.step == 1 && st.ndim == 3 && !o.bx_set && !o.by_set && !o.my_set && !o.sn_set) {
+        const int mxv = o.mx_set ? std::max(o.bmx, o.cmx) : vec_elems;
+        const int lanes = st.N / mxv;
+        if (st.N % mxv == 0 && lanes % 64 == 0 && lanes >= 64 && lanes <= 256) {
+            o.bx = lanes; o.by = 512 / lanes; o.bmy = 4; o.cmy = 1; o.sn = 4;
+            o.bx_set = o.by_set = o.my_set = o.sn_set = true;
+            if (o.prefetch_auto) o.prefetch = true;
+        }
+    }
     if (!o.ref_defaults) {
         if (!o.bx_set) o.bx = 64;
         if (!o.mx_set) { o.bmx = vec_elems; o.cmx = 1; }
@@ -93,6 +106,7 @@ inline KernelPlan make_plan(const Stencil &st, const GenOptions &o_in, const std
         // (measured: sn 8 beats sn 64 by 9 % on 3d7pt_star 1024^3, profiles/)
         if (!o.sn_set) o.sn = 8;
     }
+    p.prefetch = o.prefetch || (o_in.step > 1 && st.ndim == 3 && !o.ref_defaults && o.prefetch_auto);
     const bool bmerge_y = o.bmy > o.cmy;
     const int mx = std::max(o.bmx, o.cmx), my = std::max(o.bmy, o.cmy);
 

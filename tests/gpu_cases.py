@@ -75,7 +75,7 @@ FULL = [
     ("C4_3d7pt_1024_fp32_fused2_bench_headline", 3, os.path.join(CFG, "c4_3d7pt_star_1024.stc"),
      ["--3d", "--dtype", "fp32", "--step", "2", "--prefetch", "--bx", "64", "--by", "8", "--block-merge-x", "4", "--block-merge-y", "2", "--sn", "32", "--xcd-remap", "2"]),
     ("C4_3d7pt_1024_fp32_step1_tuned", 3, os.path.join(CFG, "c4_3d7pt_star_1024.stc"),
-     ["--3d", "--dtype", "fp32", "--bx", "64", "--by", "4", "--block-merge-x", "4", "--block-merge-y", "4", "--sn", "8", "--xcd-remap", "2"]),
+     ["--3d", "--dtype", "fp32", "--prefetch", "--bx", "256", "--by", "2", "--block-merge-x", "4", "--block-merge-y", "4", "--sn", "4", "--xcd-remap", "2"]),
     ("C5_2d25pt_16384_fp64", 2, os.path.join(CFG, "c5_2d25pt_box_16384.stc"), ["--dtype", "fp64"]),
 ]
 
