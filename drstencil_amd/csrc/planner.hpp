@@ -91,7 +91,7 @@ inline KernelPlan make_plan(const Stencil &st, const GenOptions &o_in, const std
     if (!o.ref_defaults && st.step == 1 && st.ndim == 3 && !o.bx_set && !o.by_set && !o.my_set && !o.sn_set) {
         const int mxv = o.mx_set ? std::max(o.bmx, o.cmx) : vec_elems;
         const int lanes = st.N / mxv;
-        if (st.N % mxv == 0 && lanes % 64 == 0 && lanes >= 64 && lanes <= 256) {
+        if (st.N % mxv == 0 && lanes == 256) {   // measured only there; narrower rows keep the 64-lane default (C3: full rows lose)
             o.bx = lanes; o.by = 512 / lanes; o.bmy = 4; o.cmy = 1; o.sn = 4;
             o.bx_set = o.by_set = o.my_set = o.sn_set = true;
             if (o.prefetch_auto) o.prefetch = true;
