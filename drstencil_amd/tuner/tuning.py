@@ -10,7 +10,7 @@ sweep -> per-config generate/compile/measure -> append every improvement to dura
 rocprofv3 instead of Nsight Compute:
 
   space vector = (step, dist, (bx, by), sn, unroll, blockMergeX, mx, blockMergeY, my,
-                  mergeForward, prefetch, xrim, temporal, xcd)
+                  mergeForward, prefetch, xrim, temporal, xcd, streaming)
   * bx in {16,32,64,128,256}: lanes along x; mx in {1,2,4} points per lane (16-byte
     accesses at mx=4 fp32 / 2 fp64); by*my rows per tile; sn planes per stream block
   * LDS budget 160 KiB per CU (the reference caps at 32 KiB of A100 shared memory)
@@ -42,10 +42,10 @@ elem_bytes = 4
 
 
 def FilterParams(spaceVector):
-    step, dist, blockSize, sn, s_unroll, blockMergeX, mergeFactorX, blockMergeY, mergeFactorY, m_threshold, prefetch, xrim, temporal, xcd = spaceVector
+    step, dist, blockSize, sn, s_unroll, blockMergeX, mergeFactorX, blockMergeY, mergeFactorY, m_threshold, prefetch, xrim, temporal, xcd, streaming = spaceVector
     halo = step * order
     tx = mergeFactorX * blockSize[0]
-    ty = mergeFactorY * blockSize[1] if ndim == 3 or blockSize[1] > 0 else 1
+    ty = 1 if streaming else mergeFactorY * blockSize[1]
     # LDS: 2 planes (3 for an odd number of on-chip stages) x (rows + halo pads) x (row + x halo)
     stage_halo = order if temporal else halo
     slots = 3 if (temporal and step % 2 == 1 and step > 1) else 2
@@ -63,7 +63,8 @@ def FilterParams(spaceVector):
     if dist > step * order or dist < (step - 1) * order:
         return False
     # the tile must keep rows after removing the y halo, and x halo must fit the tile
-    if ty - 2 * halo < 1 or tx < 2 * halo:
+    # (the generator keeps the reference's "Invalid configuration!" rule: 2*Halo >= tile extent is rejected)
+    if (not streaming and ty - 2 * halo < 1) or tx <= 2 * halo:
         return False
     # a wavefront is 64 lanes: idle lanes of the last wave may cost at most 6 % of the workgroup
     threads = blockSize[0] * max(blockSize[1], 1)
@@ -87,7 +88,7 @@ def FilterParams(spaceVector):
 
 
 def cfgToCommandLine(spaceVector):
-    step, dist, blockSize, sn, s_unroll, blockMergeX, mergeFactorX, blockMergeY, mergeFactorY, m_threshold, prefetch, xrim, temporal, xcd = spaceVector
+    step, dist, blockSize, sn, s_unroll, blockMergeX, mergeFactorX, blockMergeY, mergeFactorY, m_threshold, prefetch, xrim, temporal, xcd, streaming = spaceVector
     cmd = " --bx {0} --by {1} --sn {2} --stream-unroll {3}".format(blockSize[0], blockSize[1], sn, s_unroll)
     cmd += " --step {0} --dist {1}".format(step, dist)
     if blockMergeX:
@@ -104,18 +105,20 @@ def cfgToCommandLine(spaceVector):
     cmd += " --xrim {0} --xcd-remap {1}".format(xrim, xcd)
     if temporal:
         cmd += " --temporal 1"
+    if streaming:
+        cmd += " --streaming"
     return cmd
 
 
 def cfgToString(spaceVector):
-    step, dist, blockSize, sn, s_unroll, blockMergeX, mergeFactorX, blockMergeY, mergeFactorY, m_threshold, prefetch, xrim, temporal, xcd = spaceVector
+    step, dist, blockSize, sn, s_unroll, blockMergeX, mergeFactorX, blockMergeY, mergeFactorY, m_threshold, prefetch, xrim, temporal, xcd, streaming = spaceVector
     cmd = "fu{0}d{1}bx{2}y{3}sn{4}u{5}".format(step, dist, blockSize[0], blockSize[1], sn, s_unroll)
     cmd += ("bmx{0}" if blockMergeX else "cmx{0}").format(mergeFactorX)
     cmd += ("bmy{0}" if blockMergeY else "cmy{0}").format(mergeFactorY)
     cmd += "mf{0}".format(m_threshold)
     if prefetch:
         cmd += "p"
-    cmd += "x" + xrim[0] + "m" + str(xcd) + ("t" if temporal else "")
+    cmd += "x" + xrim[0] + "m" + str(xcd) + ("t" if temporal else "") + ("s" if streaming else "")
     return cmd
 
 
@@ -147,6 +150,7 @@ def enumerate_space(steps=(1,), full=False):
         ["dpp"] if not full else ["lds", "dpp"],
         [False, True],             # temporal blocking (only meaningful for step > 1)
         [0, 2] if ndim == 3 else [0],
+        [False] if ndim == 3 else [False, True],   # 2D: one-shot tile kernel or --streaming (rows streamed)
     )
     out = []
     for v in space:
@@ -154,6 +158,12 @@ def enumerate_space(steps=(1,), full=False):
         v[1] = v[0] * order
         if v[8] == 1:
             v[7] = False           # merge factor 1: cyclic == block, keep the reference's spelling
+        if ndim == 2 and not v[14]:
+            if v[3] != sns[0] or v[10]:
+                continue           # the one-shot tile kernel has no stream blocks and nothing to prefetch
+        if ndim == 2 and v[14]:
+            if v[2][1] != 1 or v[8] != 1:
+                continue           # 2D --streaming ignores by / y merging (codegen_2d.hpp:125)
         v = tuple(v)
         if FilterParams(v):
             out.append(v)
@@ -180,13 +190,19 @@ def _build(job):
         return name, False, str(e)[-400:]
 
 
+def _noop(_):
+    return os.getpid()
+
+
 def searchSpace(stc, is3d, dtype, configs, outdir, iterations=8, budget_s=None, jobs=16, extra_opts=()):
     """Sweep `configs` (space vectors or raw option strings).
 
-    Phase 1 generates + compiles every configuration (hipcc, parallel) BEFORE this process
-    touches the GPU -- a process that has initialised HIP must not fork/exec compilers.
-    Phase 2 loads and times them.  Improvements go to duration.log (seconds-since-start,
-    best ns, name), every result to results.jsonl."""
+    Generation + compilation (hipcc) runs in worker processes that are started from a fork SERVER before
+    this process touches the GPU -- a process that has initialised HIP must not fork/exec compilers, the
+    clean workers may at any time -- and overlaps with the timing of the configurations already built.
+    Improvements go to duration.log (seconds-since-start, best ns, name), every result to results.jsonl;
+    a wall-clock budget (the reference's 2D tuner stops after 3600 s) ends the sweep cleanly."""
+    import multiprocessing
     from concurrent.futures import ProcessPoolExecutor
     os.makedirs(outdir, exist_ok=True)
     startTime = datetime.datetime.now()
@@ -198,34 +214,36 @@ def searchSpace(stc, is3d, dtype, configs, outdir, iterations=8, budget_s=None, 
             named.append((cfgToString(c), cfgToCommandLine(c).split()))
     base = (["--3d"] if is3d else []) + ["--dtype", dtype] + list(extra_opts)
     jobsl = [(n, base + a + [stc]) for n, a in named]
-    built = []
-    t_start = time.time()
-    with ProcessPoolExecutor(max_workers=jobs) as ex:
-        for cnt, (name, ok, info) in enumerate(ex.map(_build, jobsl), 1):
-            if ok:
-                built.append(name)
-            else:
-                print("{0}/{1}: {2} BUILD FAILED {3}".format(cnt, len(jobsl), name, info.splitlines()[-1] if info else ""), flush=True)
-    print("built {0}/{1} configurations in {2:.0f} s".format(len(built), len(jobsl), time.time() - t_start), flush=True)
-
-    import torch
-    import drstencil_amd as drs
     argmap = dict(jobsl)
+    t_start = time.time()
+    pool = ProcessPoolExecutor(max_workers=jobs, mp_context=multiprocessing.get_context("forkserver"))
+    list(pool.map(_noop, range(jobs)))             # start the fork server and the workers now, before HIP is up
+    futures = [pool.submit(_build, j) for j in jobsl]
+
+    import drstencil_amd as drs
+    torch = None
+    A = B = None
     best = 1e18
     results = []
-    spec = drs.Spec(stc, 3 if is3d else 2, 1)
-    L, M, N = spec.dims
-    shape = (L, M, N) if is3d else (M, N)
-    tdt = torch.float32 if dtype == "fp32" else torch.float64
-    kerns = [(n, drs.Kernel(argmap[n])) for n in built]      # cache hits: no compiler runs
-    A = torch.rand(shape, dtype=tdt, device="cuda")
-    B = torch.zeros_like(A)
     esz = 4 if dtype == "fp32" else 8
-    npts = A.numel()
-    t_start = time.time()
-    for cnt, (name, kern) in enumerate(kerns, 1):
+    nfail = 0
+    for cnt, fut in enumerate(futures, 1):
+        name, ok, info = fut.result()
+        if not ok:
+            nfail += 1
+            print("{0}/{1}: {2} BUILD FAILED {3}".format(cnt, len(jobsl), name, info.splitlines()[-1] if info else ""), flush=True)
+            continue
+        kern = drs.Kernel(argmap[name])                # cache hit: no compiler runs in this process
+        if torch is None:
+            import torch
+            spec = drs.Spec(stc, 3 if is3d else 2, 1)
+            L, M, N = spec.dims
+            shape = (L, M, N) if is3d else (M, N)
+            tdt = torch.float32 if dtype == "fp32" else torch.float64
+            A = torch.rand(shape, dtype=tdt, device="cuda")
+            B = torch.zeros_like(A)
         dur = measure(kern, torch, A, B, iterations)
-        gbs = 2.0 * esz * npts / dur
+        gbs = 2.0 * esz * A.numel() / dur
         gst = kern.updates_per_launch() / dur
         rec = dict(name=name, args=" ".join(argmap[name][:-1]), duration_ns=dur, GBps=gbs, frac=gbs / 8000.0, GStencil=gst,
                    lds=kern.info["lds_bytes"], threads=kern.info["threads"], step=kern.info["step"])
@@ -233,14 +251,17 @@ def searchSpace(stc, is3d, dtype, configs, outdir, iterations=8, budget_s=None, 
         with open(os.path.join(outdir, "results.jsonl"), "a") as f:
             f.write(json.dumps(rec) + "\n")
         print("{0}/{1}: {2}  {3:.0f} ns  {4:.0f} GB/s ({5:.1f}%)  {6:.1f} GStencil/s".format(
-            cnt, len(kerns), name, dur, gbs, gbs / 80.0, gst), flush=True)
+            cnt, len(jobsl), name, dur, gbs, gbs / 80.0, gst), flush=True)
         if dur < best:
             best = dur
             with open(os.path.join(outdir, "duration.log"), "a") as f:
                 f.write(str((datetime.datetime.now() - startTime).seconds) + " s, " + str(int(best)) + ", " + name + "\n")
         if budget_s and time.time() - t_start > budget_s:
-            print("time budget reached", flush=True)
+            print("time budget reached after {0} of {1} configurations".format(cnt, len(jobsl)), flush=True)
+            for f in futures[cnt:]:
+                f.cancel()
             break
+    pool.shutdown(wait=False, cancel_futures=True)
     with open(os.path.join(outdir, "duration.log"), "a") as f:
         f.write(str((datetime.datetime.now() - startTime).seconds) + " s, " + str(int(best)) + "\n")
     results.sort(key=lambda r: r["duration_ns"])

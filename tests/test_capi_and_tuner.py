@@ -71,11 +71,11 @@ def test_kernel_info_and_work_model():
 def test_tuner_space_and_naming():
     from drstencil_amd.tuner import tuning as t
     t.order, t.ndim, t.elem_bytes = 1, 3, 4
-    v = (2, 1, (16, 8), 8, 4, False, 1, False, 1, 5, False, "lds", False, 2)
+    v = (2, 1, (16, 8), 8, 4, False, 1, False, 1, 5, False, "lds", False, 2, False)
     # reference naming/command-line scheme (benchmarks/3d7pt_star/tuning.py:40-78) + our suffix
     assert t.cfgToString(v).startswith("fu2d1bx16y8sn8u4cmx1cmy1mf5")
     assert t.cfgToCommandLine(v).startswith(" --bx 16 --by 8 --sn 8 --stream-unroll 4 --step 2 --dist 1 --cyclic-merge-x 1 --cyclic-merge-y 1 --merge-forward 5")
-    vp = v[:10] + (True, "dpp", True, 0)
+    vp = v[:10] + (True, "dpp", True, 0, False)
     assert t.cfgToString(vp).startswith("fu2d1bx16y8sn8u4cmx1cmy1mf5p")
     space = t.enumerate_space((1, 2))
     assert len(space) > 100
@@ -83,12 +83,24 @@ def test_tuner_space_and_naming():
     names = [t.cfgToString(s) for s in space]
     assert len(set(names)) == len(names)
     # filter rules: dist range, LDS budget, wavefront multiple
-    assert not t.FilterParams((2, 3, (64, 4), 64, 4, True, 4, True, 4, 5, False, "lds", False, 2))   # dist > step*order
-    assert not t.FilterParams((1, 1, (16, 2), 64, 4, True, 4, True, 4, 5, False, "lds", False, 2))   # 32 lanes: half a wave
-    assert not t.FilterParams((1, 1, (256, 4), 64, 4, True, 4, True, 8, 5, False, "lds", False, 2))  # LDS over 160 KiB
-    assert not t.FilterParams((1, 1, (66, 15), 32, 4, True, 4, True, 2, 5, False, "dpp", False, 0))  # odd lane count without temporal
-    assert t.FilterParams((2, 2, (66, 15), 32, 4, True, 4, True, 2, 5, True, "dpp", True, 0))        # the bench configuration
-    assert t.FilterParams((1, 1, (64, 4), 64, 4, True, 4, True, 4, 5, False, "lds", False, 2))
+    assert not t.FilterParams((2, 3, (64, 4), 64, 4, True, 4, True, 4, 5, False, "lds", False, 2, False))   # dist > step*order
+    assert not t.FilterParams((1, 1, (16, 2), 64, 4, True, 4, True, 4, 5, False, "lds", False, 2, False))   # 32 lanes: half a wave
+    assert not t.FilterParams((1, 1, (256, 4), 64, 4, True, 4, True, 8, 5, False, "lds", False, 2, False))  # LDS over 160 KiB
+    assert not t.FilterParams((1, 1, (66, 15), 32, 4, True, 4, True, 2, 5, False, "dpp", False, 0, False))  # odd lane count without temporal
+    assert t.FilterParams((2, 2, (66, 15), 32, 4, True, 4, True, 2, 5, True, "dpp", True, 0, False))        # the bench configuration
+    assert t.FilterParams((1, 1, (64, 4), 64, 4, True, 4, True, 4, 5, False, "lds", False, 2, False))
+    # 2D space: tile and --streaming kernels
+    t.order, t.ndim, t.elem_bytes = 1, 2, 4
+    sp2 = t.enumerate_space((1, 2))
+    assert any(v[14] for v in sp2) and any(not v[14] for v in sp2)
+    assert all(("--streaming" in t.cfgToCommandLine(v)) == v[14] for v in sp2)
+    stc2 = os.path.join(ROOT, "benchmarks", "2d5pt_star", "2d5pt_star.stc")
+    import random
+    random.seed(1)
+    for s2 in random.sample(sp2, 20):
+        rc, msg, src = drs.generate(["--dtype", "fp32"] + t.cfgToCommandLine(s2).split() + [stc2])
+        assert rc == 0 and src, (t.cfgToString(s2), msg)
+    t.order, t.ndim, t.elem_bytes = 1, 3, 4
     # every configuration of the space is accepted by the generator
     stc = os.path.join(ROOT, "benchmarks", "3d7pt_star", "3d7pt_star.stc")
     import random
