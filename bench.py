@@ -49,7 +49,7 @@ TUNED = {
 # search (profiles/r01_tune_c4_s1_exhaustive.txt) -- 80 % of the HBM peak, the chip's measured copy ceiling
 STEP1 = {
     "c4": ["--3d", "--dtype", "fp32", "--prefetch", "--bx", "256", "--by", "2", "--block-merge-x", "4", "--block-merge-y", "4", "--sn", "4", "--xcd-remap", "2"],
-    "c3": ["--3d", "--dtype", "fp32", "--bx", "64", "--by", "4", "--block-merge-x", "4", "--block-merge-y", "4", "--sn", "8", "--xcd-remap", "1"],
+    "c3": ["--3d", "--dtype", "fp32", "--prefetch", "--bx", "32", "--by", "16", "--block-merge-x", "4", "--block-merge-y", "2", "--sn", "4", "--xcd-remap", "2"],
 }
 # on-chip temporal blocking (two applications of the one-step stencil per launch; equal to the fused stencil up to
 # rounding, 6.8e-7 relative at full size): 66 lanes x 4 = 264 columns own 256, so 4 tiles cover N = 1024 exactly
