@@ -40,7 +40,7 @@ WORKLOADS = {
 # temporal pipeline within a few per cent of each other; their order changes from device to device.
 TUNED = {
     "c4": ["--3d", "--dtype", "fp32", "--step", "2", "--prefetch", "--bx", "64", "--by", "8", "--block-merge-x", "4", "--block-merge-y", "2", "--sn", "32", "--xcd-remap", "2"],
-    "c3": ["--3d", "--dtype", "fp32", "--step", "2", "--prefetch", "--bx", "32", "--by", "8", "--block-merge-x", "4", "--block-merge-y", "2", "--sn", "32", "--xcd-remap", "2"],
+    "c3": ["--3d", "--dtype", "fp32", "--step", "2", "--prefetch", "--bx", "32", "--by", "16", "--block-merge-x", "4", "--block-merge-y", "2", "--sn", "32", "--xcd-remap", "2"],
     "c2": ["--dtype", "fp32", "--bx", "64", "--by", "4", "--block-merge-x", "4", "--block-merge-y", "8", "--xcd-remap", "0"],
     "c5": ["--dtype", "fp64", "--bx", "64", "--by", "4", "--block-merge-x", "2", "--block-merge-y", "8", "--xcd-remap", "0", "--clamp-loads", "0"],
 }
