@@ -41,8 +41,10 @@ WORKLOADS = {
 TUNED = {
     "c4": ["--3d", "--dtype", "fp32", "--step", "2", "--prefetch", "--bx", "64", "--by", "8", "--block-merge-x", "4", "--block-merge-y", "2", "--sn", "32", "--xcd-remap", "2"],
     "c3": ["--3d", "--dtype", "fp32", "--step", "2", "--prefetch", "--bx", "32", "--by", "16", "--block-merge-x", "4", "--block-merge-y", "2", "--sn", "32", "--xcd-remap", "2"],
-    "c2": ["--dtype", "fp32", "--bx", "64", "--by", "4", "--block-merge-x", "4", "--block-merge-y", "8", "--xcd-remap", "0"],
-    "c5": ["--dtype", "fp64", "--bx", "64", "--by", "4", "--block-merge-x", "2", "--block-merge-y", "8", "--xcd-remap", "0", "--clamp-loads", "0"],
+    # 2D one-shot LDS tiles (BASELINE C2 "no temporal blocking (baseline LDS tile)", C5 "wide-halo LDS staging"): best of the
+    # exhaustive 2D searches, profiles/r01_tune_c2_exhaustive.txt / r01_tune_c5_exhaustive.txt (0.78 of the HBM peak each)
+    "c2": ["--dtype", "fp32", "--bx", "128", "--by", "2", "--block-merge-x", "4", "--block-merge-y", "2", "--xcd-remap", "0"],
+    "c5": ["--dtype", "fp64", "--bx", "64", "--by", "4", "--block-merge-x", "2", "--block-merge-y", "4", "--xcd-remap", "0"],
 }
 # the same workloads with one time step per launch: highest roofline fraction.  Full-row tiles (256 lanes x 4
 # points = N), 2 lane rows x 4 rows, 4-plane stream blocks, prefetch: the optimum of the exhaustive 1520-configuration
