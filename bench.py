@@ -67,12 +67,12 @@ def kernel_arg_sets():
     return [TUNED[w] + [WORKLOADS[w]["stc"]] for w in ("c4", "c3", "c2", "c5")] + [STEP1[w] + [WORKLOADS[w]["stc"]] for w in ("c4", "c3")] + [TEMPORAL2[w] + [WORKLOADS[w]["stc"]] for w in ("c4", "c3")]
 
 
-def pmc_traffic(option_string):
-    """HBM bytes per launch of this exact kernel configuration from the committed rocprofv3 PMC passes
-    (FETCH_SIZE x 2 + WRITE_SIZE, profiles/traffic_by_options.json); None when it was not profiled."""
+def pmc_traffic(workload, option_string):
+    """HBM bytes per launch of this exact workload + kernel configuration from the committed rocprofv3 PMC
+    passes (FETCH_SIZE x 2 + WRITE_SIZE, profiles/traffic_by_options.json); None when it was not profiled."""
     try:
         m = json.load(open(os.path.join(ROOT, "profiles", "traffic_by_options.json")))
-        return m[option_string]["traffic_bytes_per_launch"]
+        return m[workload][option_string]["traffic_bytes_per_launch"]
     except Exception:
         return None
 
@@ -249,7 +249,7 @@ def main():
                        "launches_per_step": launches_per_step, "parallelism": parallelism,
                        "kernel": "dr_" + kinfo["name"], "threads": kinfo["threads"], "lds_bytes": kinfo["lds_bytes"]},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(" ".join(opts)) if world == 1 else None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(args.workload, " ".join(opts)) if world == 1 else None,
                          "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": avg_launch_s * 1e3},
         }
         out["step1_kernel"] = step1                 # one time step per launch: highest roofline fraction
