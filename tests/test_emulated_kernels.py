@@ -149,3 +149,33 @@ def test_emulated_reverse_fiber_order(vid, ndim, pts, dims, opts, tmp_path, monk
     oracle.run(spec, A2, B2, contract=1)
     run_emulated(lib, A, B, spec.iterations, step)
     assert oracle.check(spec, A, A2)["max_rel"] < 1e-12 and oracle.check(spec, B, B2)["max_rel"] < 1e-12
+
+
+ASYM = [
+    # forward-only taps (zl = 0, no -x/-y halo): PADL = 0, no rows above
+    ("3d_forward_only", 3, [(0, 0, 0, 0.4), (1, 0, 0, 0.1), (2, 0, 0, 0.05), (0, 1, 0, 0.2), (0, 0, 1, 0.15), (0, 0, 2, 0.1)], (14, 13, 140), ["--3d", "--dtype", "fp64", "--sn", "5", "--dist", "1"]),
+    # different reach per dimension (hx = 2, hy = 1, hz = 2), not symmetric in x
+    ("3d_mixed_reach", 3, [(0, 0, 0, 0.3), (-2, 0, 0, 0.1), (2, 0, 0, 0.1), (1, 0, 0, 0.05), (0, -1, 0, 0.2), (0, 1, 0, 0.1), (0, 0, -2, 0.05), (0, 0, 1, 0.1)], (15, 12, 150), ["--3d", "--dtype", "fp32", "--sn", "4", "--prefetch", "--dist", "2"]),
+    ("3d_mixed_reach_temporal", 3, [(0, 0, 0, 0.3), (-1, 0, 0, 0.1), (1, 0, 0, 0.1), (0, -1, 0, 0.2), (0, 1, 0, 0.1), (0, 0, -1, 0.05), (0, 0, 1, 0.15)], (15, 17, 150), ["--3d", "--dtype", "fp64", "--sn", "4", "--step", "2", "--temporal", "1", "--by", "4", "--block-merge-y", "2"]),
+    ("2d_upwind_rows", 2, [(0, 0, 0.5), (1, 0, 0.2), (2, 0, 0.1), (0, 1, 0.1), (0, 2, 0.1)], (1, 33, 70), ["--dtype", "fp64", "--dist", "1"]),
+    ("2d_upwind_rows_stream", 2, [(0, 0, 0.5), (1, 0, 0.2), (2, 0, 0.1), (0, 1, 0.1), (0, 2, 0.1)], (1, 33, 70), ["--dtype", "fp32", "--streaming", "--sn", "6", "--dist", "1", "--xrim", "lds"]),
+]
+
+
+@pytest.mark.parametrize("vid,ndim,pts,dims,opts", ASYM, ids=[v[0] for v in ASYM])
+def test_emulated_asymmetric_stencils(vid, ndim, pts, dims, opts, tmp_path):
+    """Stencils that are not symmetric: one-sided taps, different reach per dimension."""
+    stc = str(tmp_path / "a.stc")
+    write_stc(stc, ndim, dims, 4, pts)
+    step = int(opts[opts.index("--step") + 1]) if "--step" in opts else 1
+    lib = build_emulated(tmp_path, stc, opts)
+    spec = oracle.Spec(stc, ndim, step)
+    dt = np.float32 if "fp32" in opts else np.float64
+    A = oracle.fill_random(spec.shape, dt); B = np.zeros_like(A)
+    A2, B2 = A.copy(), B.copy()
+    oracle.run(spec, A2, B2, contract=1)
+    assert run_emulated(lib, A, B, spec.iterations, step) == spec.launches
+    if "--temporal" in opts:
+        assert oracle.check(spec, A, A2)["max_rel"] < 1e-12 and oracle.check(spec, B, B2)["max_rel"] < 1e-12
+    else:
+        assert np.array_equal(A, A2) and np.array_equal(B, B2)
