@@ -9,10 +9,19 @@ the global frozen ring stays on the outer faces of rank 0 and rank R-1, every la
 <= 2 neighbours, and both ping-pong buffers carry H ghost planes per interior face.
 
 Per launch and rank (boundary first, so the exchange overlaps the interior sweep):
-    main stream : boundary kernels (first/last H owned planes)      -> event b
-    comm stream : wait b; batch_isend_irecv of dst's boundary planes -> event c
-    main stream : interior kernel; wait c (next launch reads dst's ghost planes)
-Each neighbour pair talks over its own xGMI link; nothing is all-reduced in the loop.
+    main stream : boundary kernels (first/last H owned planes) -> event b ; interior kernel ; wait c
+    side stream : wait b; batch_isend_irecv of dst's boundary planes -> event c
+Three things measured with scripts/rccl_probe.py (profiles/r01_rccl_probe.md) shape this:
+  * the interior kernel is enqueued BEFORE the RCCL call is made -- batch_isend_irecv costs ~100 us of host time
+    per call and the GPU idles through it otherwise;
+  * the side stream and RCCL's own stream are high priority (init the process group with
+    ProcessGroupNCCL.Options(is_high_priority_stream=True), see nccl_options()): HIP multiplexes streams of one
+    priority onto a few in-order hardware queues, and an RCCL kernel that lands on the interior kernel's queue
+    runs only after it;
+  * the boundary kernels stay in front of the interior kernel on the same stream (2 x 10 us): beside it they wait
+    55 us each for the long-lived stream blocks of the interior kernel to release their CUs.
+Critical path per launch = boundary + max(interior, exchange).  Each neighbour pair talks over its own xGMI link;
+nothing is all-reduced in the loop.
 
 Kernels are ordinary generated kernels: a z sub-range of a slab is a contiguous view, so
 a "boundary kernel" is the generator's kernel for L = 3H planes and the interior kernel
@@ -78,6 +87,14 @@ def _write_view_stc(base_stc, ndim, L_view, cache_dir, tag):
     return path
 
 
+def nccl_options(dist):
+    """Process-group options for the slab run: RCCL's internal stream must not share an in-order hardware queue
+    with the interior kernel's stream (it would run only after it), so it is created high priority."""
+    o = dist.ProcessGroupNCCL.Options()
+    o.is_high_priority_stream = True
+    return o
+
+
 class HipSweep:
     """Product sweep backend: generated HIP kernel for a view of Lv planes."""
 
@@ -119,7 +136,7 @@ class SlabRun:
         self.B = torch.zeros((p.Lloc,) + self.rest, dtype=dtype, device=device)
         if self.gpu:
             self.main = torch.cuda.current_stream(device)
-            self.comm = torch.cuda.Stream(device=device)
+            self.side = torch.cuda.Stream(device=device, priority=-1)
             self.ev_b = torch.cuda.Event()
             self.ev_c = torch.cuda.Event()
         self.launch_count = 0
@@ -148,26 +165,30 @@ class SlabRun:
             w.wait()
 
     def launch(self, src, dst):
-        """One launch src -> dst with halo exchange of dst (boundary first)."""
+        """One launch src -> dst with halo exchange of dst."""
         p, H = self.plan, self.H
-        sh = self._stream_handle()
-        for v in (p.top, p.bot):
-            if v is not None:
-                self.sweep(src[v[0]:v[1]], dst[v[0]:v[1]], sh)
-        if self.world > 1:
-            if self.gpu:
-                self.ev_b.record(self.main)
-                with self.torch.cuda.stream(self.comm):
-                    self.comm.wait_event(self.ev_b)
-                    self._exchange(dst)
-                    self.ev_c.record(self.comm)
         a, b = p.interior
-        if b - a > 2 * H:
-            self.sweep(src[a:b], dst[a:b], sh)
-        if self.world > 1:
-            if self.gpu:
-                self.main.wait_event(self.ev_c)
-            else:
+        if self.gpu and self.world > 1:
+            sh = self.main.cuda_stream
+            for v in (p.top, p.bot):
+                if v is not None:
+                    self.sweep(src[v[0]:v[1]], dst[v[0]:v[1]], sh)
+            self.ev_b.record(self.main)
+            if b - a > 2 * H:
+                self.sweep(src[a:b], dst[a:b], sh)
+            with self.torch.cuda.stream(self.side):
+                self.side.wait_event(self.ev_b)
+                self._exchange(dst)
+                self.ev_c.record(self.side)
+            self.main.wait_event(self.ev_c)
+        else:
+            sh = self._stream_handle()
+            for v in (p.top, p.bot):
+                if v is not None:
+                    self.sweep(src[v[0]:v[1]], dst[v[0]:v[1]], sh)
+            if b - a > 2 * H:
+                self.sweep(src[a:b], dst[a:b], sh)
+            if self.world > 1:
                 self._exchange(dst)
         self.launch_count += 1
 

@@ -258,6 +258,8 @@ class _FakeDist:
                 self.hub.mail.setdefault((self.rank, o.peer), []).append(o.tensor.clone())
             else:
                 self.hub.pending.append(((o.peer, self.rank), o.tensor))
+        import torch
+        torch.cuda.current_stream().synchronize()   # the clones are complete before any rank's stream copies them
         self.hub.deliver()
         return [self._Work() for _ in ops]
 
