@@ -305,3 +305,54 @@ def test_slab_decomposition_on_one_gpu(torch_cuda, world, opts, tmp_path):
         p = r.plan
         assert np.array_equal(r.owned(r.A).cpu().numpy(), A_ref[p.z0:p.z1]), "rank %d A" % r.rank
         assert np.array_equal(r.owned(r.B).cpu().numpy(), B_ref[p.z0:p.z1]), "rank %d B" % r.rank
+
+
+def test_rccl_exchange_choreography_on_one_gpu(torch_cuda, tmp_path):
+    """The real RCCL transport under SlabRun's stream/event choreography, as far as one GPU can show it: this
+    process is the only rank of an RCCL group and plays a middle rank whose two neighbours are itself (what it
+    sends "up" arrives in its lower ghost planes and vice versa).  The run with batch_isend_irecv on RCCL's own
+    streams must equal, bit for bit, the same run whose exchange is two plain device copies on the side stream --
+    a missing event / wrong stream order shows up as stale ghost planes."""
+    import torch.distributed as dist
+    import drstencil_amd as drs
+    from drstencil_amd.multigpu import HipSweep, SlabRun, nccl_options
+    from gpu_cases import stc as stcp
+    torch = torch_cuda
+    opts = ["--3d", "--dtype", "fp32", "--step", "2", "--sn", "16"]
+    stc = stcp("t3_star")
+    spec = oracle.Spec(stc, 3, 2)
+    L, M, N = spec.dims
+    H = spec.halo
+    dev = torch.device("cuda", 0)
+    sweep = HipSweep(stc, opts, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "drstencil_amd", "_kcache"))
+    dist.init_process_group("nccl", store=dist.FileStore(str(tmp_path / "store"), 1), rank=0, world_size=1,
+                            device_id=dev, pg_options=nccl_options(dist))
+    try:
+        class SelfRccl(SlabRun):
+            def _exchange(self, dst):
+                p = self.plan
+                ops = [dist.P2POp(dist.isend, dst[p.send_up[0]:p.send_up[1]], 0), dist.P2POp(dist.irecv, dst[p.recv_dn[0]:p.recv_dn[1]], 0),
+                       dist.P2POp(dist.isend, dst[p.send_dn[0]:p.send_dn[1]], 0), dist.P2POp(dist.irecv, dst[p.recv_up[0]:p.recv_up[1]], 0)]
+                for wk in dist.batch_isend_irecv(ops):
+                    wk.wait()
+
+        class SelfCopy(SlabRun):
+            def _exchange(self, dst):
+                p = self.plan
+                dst[p.recv_dn[0]:p.recv_dn[1]].copy_(dst[p.send_up[0]:p.send_up[1]])
+                dst[p.recv_up[0]:p.recv_up[1]].copy_(dst[p.send_dn[0]:p.send_dn[1]])
+
+        A0 = torch.as_tensor(oracle.fill_random(spec.shape, np.float32))
+        res = []
+        for cls in (SelfRccl, SelfCopy):
+            run = cls(torch, dist, (L, M, N), H, 2, 24, 1, 3, sweep, dev, torch.float32)   # middle rank of 3
+            run.load_global(lambda lo, hi: A0[lo:hi])
+            n = run.run()
+            torch.cuda.synchronize()
+            assert n == 12
+            res.append((run.A.clone(), run.B.clone(), run.plan))
+        (a1, b1, p), (a2, b2, _) = res
+        assert torch.equal(a1, a2) and torch.equal(b1, b2)
+        assert bool((a1[p.recv_up[0]:p.recv_up[1]] != A0[p.lo:p.lo + H].to(dev)).any()), "ghost planes were never exchanged"
+    finally:
+        dist.destroy_process_group()
