@@ -59,6 +59,11 @@ TEMPORAL2 = {
     "c4": ["--3d", "--dtype", "fp32", "--step", "2", "--temporal", "1", "--prefetch", "--bx", "66", "--by", "15", "--block-merge-x", "4", "--block-merge-y", "2", "--sn", "32", "--xcd-remap", "0"],
     "c3": ["--3d", "--dtype", "fp32", "--step", "2", "--temporal", "1", "--prefetch", "--bx", "66", "--by", "15", "--block-merge-x", "4", "--block-merge-y", "2", "--sn", "16", "--xcd-remap", "0"],
 }
+# N > 1 (z slabs of C4): the same fused kernel with 16-plane stream blocks -- a 128/256-plane slab view has too few
+# 32-plane blocks to keep 256 CUs evenly busy (256-plane view: 0.404 ms vs 0.453 ms, profiles/r01_exp_r1y_slab_views.log)
+SLAB = {
+    "c4": ["--3d", "--dtype", "fp32", "--step", "2", "--prefetch", "--bx", "64", "--by", "8", "--block-merge-x", "4", "--block-merge-y", "2", "--sn", "16", "--xcd-remap", "2"],
+}
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak (MI355X_MICROARCH.md: 8.0 TB/s spec)
 
 
@@ -136,7 +141,7 @@ def main():
     # Generate + compile (or find cached) every kernel BEFORE HIP is initialised: a process
     # that has touched the GPU must not fork/exec the compiler.
     w = WORKLOADS[args.workload]
-    opts = args.kernel_args.split() if args.kernel_args else TUNED[args.workload]
+    opts = args.kernel_args.split() if args.kernel_args else (SLAB.get(args.workload, TUNED[args.workload]) if world > 1 else TUNED[args.workload])
     spec = drs.Spec(w["stc"], w["ndim"], int(opts[opts.index("--step") + 1]) if "--step" in opts else 1)
     L, M, N = spec.dims
     H, step, iters = spec.halo, spec.step, spec.iterations
