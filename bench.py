@@ -33,14 +33,16 @@ WORKLOADS = {
 }
 # tuned generator options per workload (found with drstencil_amd/tuner; logs under profiles/).
 # Headline for the 3D workloads: two time steps per launch with the reference's own --step 2 arithmetic
-# (algebraically fused 25-point stencil, one pass) -- bit-identical to the oracle.  One wavefront (64 lanes x
-# 4 points) per row, 8 lane rows x 2 rows (16 x 256 tile, halo fetched by the halo loader lanes), 32-plane
-# stream blocks, software prefetch, one x-y band per XCD.  The exhaustive 1780-configuration search
+# (algebraically fused 25-point stencil, one pass) -- bit-identical to the oracle.  32 lanes x 4 points per row,
+# 16 lane rows x 2 rows (32 x 128 tile, halo fetched by the halo loader lanes), 32-plane stream blocks, three
+# planes in flight per lane (software prefetch depth 3: the 200+ VGPRs of the fused kernel leave one workgroup
+# per CU, so the bytes in flight have to come from depth -- profiles/r01_exp_r1z*_prefetch_depth.log), one x-y
+# band per XCD.  The exhaustive 1780-configuration search
 # (profiles/r01_tune_c4_s2_exhaustive.txt) puts the 32x16-lane and 64x8-lane fused kernels and the 66x15-lane
 # temporal pipeline within a few per cent of each other; their order changes from device to device.
 TUNED = {
-    "c4": ["--3d", "--dtype", "fp32", "--step", "2", "--prefetch", "--bx", "64", "--by", "8", "--block-merge-x", "4", "--block-merge-y", "2", "--sn", "32", "--xcd-remap", "2"],
-    "c3": ["--3d", "--dtype", "fp32", "--step", "2", "--prefetch", "--bx", "32", "--by", "16", "--block-merge-x", "4", "--block-merge-y", "2", "--sn", "32", "--xcd-remap", "2"],
+    "c4": ["--3d", "--dtype", "fp32", "--step", "2", "--prefetch", "--prefetch-depth", "3", "--bx", "32", "--by", "16", "--block-merge-x", "4", "--block-merge-y", "2", "--sn", "32", "--xcd-remap", "2"],
+    "c3": ["--3d", "--dtype", "fp32", "--step", "2", "--prefetch", "--prefetch-depth", "3", "--bx", "32", "--by", "16", "--block-merge-x", "4", "--block-merge-y", "2", "--sn", "32", "--xcd-remap", "2"],
     # 2D one-shot LDS tiles (BASELINE C2 "no temporal blocking (baseline LDS tile)", C5 "wide-halo LDS staging"): best of the
     # exhaustive 2D searches, profiles/r01_tune_c2_exhaustive.txt / r01_tune_c5_exhaustive.txt (0.78 of the HBM peak each)
     "c2": ["--dtype", "fp32", "--bx", "128", "--by", "2", "--block-merge-x", "4", "--block-merge-y", "2", "--xcd-remap", "0"],
@@ -59,11 +61,16 @@ TEMPORAL2 = {
     "c4": ["--3d", "--dtype", "fp32", "--step", "2", "--temporal", "1", "--prefetch", "--bx", "66", "--by", "15", "--block-merge-x", "4", "--block-merge-y", "2", "--sn", "32", "--xcd-remap", "0"],
     "c3": ["--3d", "--dtype", "fp32", "--step", "2", "--temporal", "1", "--prefetch", "--bx", "66", "--by", "15", "--block-merge-x", "4", "--block-merge-y", "2", "--sn", "16", "--xcd-remap", "0"],
 }
-# N > 1 (z slabs of C4): the same fused kernel with 16-plane stream blocks -- a 128/256-plane slab view has too few
-# 32-plane blocks to keep 256 CUs evenly busy (256-plane view: 0.404 ms vs 0.453 ms, profiles/r01_exp_r1y_slab_views.log)
-SLAB = {
-    "c4": ["--3d", "--dtype", "fp32", "--step", "2", "--prefetch", "--bx", "64", "--by", "8", "--block-merge-x", "4", "--block-merge-y", "2", "--sn", "16", "--xcd-remap", "2"],
-}
+# N > 1 (z slabs of C4): the same fused kernel; slabs of 256 planes or fewer get 16-plane stream blocks -- too few
+# 32-plane blocks to keep 256 CUs evenly busy (256-plane view 0.394 ms vs 0.453 ms; 512-plane view 0.769 ms with 32
+# vs 0.808 ms with 16: profiles/r01_exp_r1y_slab_views.log, r01_exp_r1zc_slab_views_depth.log)
+def slab_options(workload, world):
+    opts = list(TUNED[workload])
+    if workload == "c4" and world >= 4:
+        opts[opts.index("--sn") + 1] = "16"
+    return opts
+
+
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak (MI355X_MICROARCH.md: 8.0 TB/s spec)
 
 
@@ -141,7 +148,7 @@ def main():
     # Generate + compile (or find cached) every kernel BEFORE HIP is initialised: a process
     # that has touched the GPU must not fork/exec the compiler.
     w = WORKLOADS[args.workload]
-    opts = args.kernel_args.split() if args.kernel_args else (SLAB.get(args.workload, TUNED[args.workload]) if world > 1 else TUNED[args.workload])
+    opts = args.kernel_args.split() if args.kernel_args else (slab_options(args.workload, world) if world > 1 else TUNED[args.workload])
     spec = drs.Spec(w["stc"], w["ndim"], int(opts[opts.index("--step") + 1]) if "--step" in opts else 1)
     L, M, N = spec.dims
     H, step, iters = spec.halo, spec.step, spec.iterations

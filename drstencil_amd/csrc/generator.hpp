@@ -147,6 +147,7 @@ inline GenResult generate(const std::vector<std::string> &args /* argv[1..] */) 
         else if (a == "--halo-spread") { if (!int_opt(o.halo_spread, nullptr)) break; }
         else if (a == "--zgroup") { if (!int_opt(o.zgroup, nullptr)) break; }
         else if (a == "--prefetch-auto") { if (!int_opt(o.prefetch_auto, nullptr)) break; }
+        else if (a == "--prefetch-depth") { if (!int_opt(o.prefetch_depth, nullptr)) break; }
         else if (a == "--temporal") { if (!int_opt(o.temporal, nullptr)) break; }
         else if (a == "--lazy-rims") { if (!int_opt(o.lazy_rims, nullptr)) break; }
         else if (a == "--xcd-remap") { if (!int_opt(o.xcd_remap, nullptr)) break; }

@@ -66,6 +66,9 @@ struct GenOptions {
     int xedge_select = 0;        // --xrim dpp: wavefront-edge lanes take the LDS value by select instead of a branch
     int zgroup = 4;              // --xcd-remap 3: stream blocks of one tile taken by consecutive workgroups
     int prefetch_auto = 1;       // 3D kernels with step > 1 (fused or temporal) prefetch unless --prefetch-auto 0 (+28 % measured)
+    int prefetch_depth = -1;     // planes in flight ahead of the one being summed (register sets = depth + 1); -1 auto:
+                                 // 2 for fused multi-step 3D kernels (their wide halo leaves one resident workgroup per CU and
+                                 // too few bytes in flight: 1.66 -> 1.56 ms on a slow-memory device, +1 % on a fast one), else 1
     int temporal = 0;            // step > 1: apply the one-step stencil `step` times on chip instead of the fused stencil
     std::string schedule = "scatter";  // scatter: partial sums carried in VGPRs; window: rotating register windows
 };
@@ -106,6 +109,7 @@ struct KernelPlan {
     int SROW = 0, SROWS = 0, NSLOT = 2;  // LDS row length, rows per plane, plane slots
     int UN = 1;              // unroll of the streaming loop
     bool prefetch = false;
+    int PD = 1;              // prefetch depth (planes in flight)
     std::string error;       // non-empty: invalid configuration
 };
 

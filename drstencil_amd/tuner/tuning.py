@@ -101,7 +101,7 @@ def cfgToCommandLine(spaceVector):
         cmd += " --cyclic-merge-y {0}".format(mergeFactorY)
     cmd += " --merge-forward {0}".format(m_threshold)
     if prefetch:
-        cmd += " --prefetch"
+        cmd += " --prefetch --prefetch-depth {0}".format(int(prefetch))   # planes in flight (True == 1)
     cmd += " --xrim {0} --xcd-remap {1}".format(xrim, xcd)
     if temporal:
         cmd += " --temporal 1"
@@ -117,7 +117,7 @@ def cfgToString(spaceVector):
     cmd += ("bmy{0}" if blockMergeY else "cmy{0}").format(mergeFactorY)
     cmd += "mf{0}".format(m_threshold)
     if prefetch:
-        cmd += "p"
+        cmd += "p" if int(prefetch) == 1 else "p{0}".format(int(prefetch))
     cmd += "x" + xrim[0] + "m" + str(xcd) + ("t" if temporal else "") + ("s" if streaming else "")
     return cmd
 
@@ -146,7 +146,7 @@ def enumerate_space(steps=(1,), full=False):
         [True], [vec] if not full else [vec // 2, vec],
         [True], mys,
         [5],
-        [False, True],             # prefetch
+        [0, 1, 3] if ndim == 3 else [0, 1],   # software prefetch: planes in flight (0 = off)
         ["dpp"] if not full else ["lds", "dpp"],
         [False, True],             # temporal blocking (only meaningful for step > 1)
         [0, 2] if ndim == 3 else [0],

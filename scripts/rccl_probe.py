@@ -32,7 +32,7 @@ def main():
     import drstencil_amd as drs
     from drstencil_amd.multigpu import HipSweep, SlabPlan, SlabRun
     w = bench.WORKLOADS[a.workload]
-    opts = bench.SLAB[a.workload]
+    opts = bench.slab_options(a.workload, a.world)
     spec = drs.Spec(w["stc"], w["ndim"], 2)
     L, M, N = spec.dims
     H, step, iters = spec.halo, spec.step, spec.iterations

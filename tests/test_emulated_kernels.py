@@ -58,6 +58,9 @@ VARIANTS = [
     ("2d25_tile_fp64", 2, "BOX25", (1, 61, 268), ["--dtype", "fp64"]),
     ("2d25_stream_step2", 2, "BOX25", (1, 61, 268), ["--dtype", "fp32", "--streaming", "--sn", "9", "--step", "2", "--prefetch"]),
     ("2d_refdefaults", 2, "BOX9", (1, 41, 70), ["--dtype", "fp64", "--ref-defaults"]),
+    ("3d_step2_prefetch_depth2", 3, "STAR3", (23, 21, 300), ["--3d", "--dtype", "fp32", "--sn", "7", "--step", "2", "--prefetch", "--prefetch-depth", "2"]),
+    ("3d_step1_prefetch_depth3", 3, "STAR3", (19, 23, 270), ["--3d", "--dtype", "fp64", "--sn", "5", "--prefetch", "--prefetch-depth", "3", "--xrim", "lds"]),
+    ("2d_stream_prefetch_depth2", 2, "STAR2", (1, 75, 530), ["--dtype", "fp32", "--streaming", "--prefetch", "--prefetch-depth", "2", "--sn", "3"]),
 ]
 
 
@@ -94,6 +97,7 @@ EDGE = [
     ("2d_stream_min", 2, "STAR2", (1, 3, 9), ["--dtype", "fp32", "--streaming", "--sn", "1"]),
     ("2d_temporal2_tile_small", 2, "BOX9", (1, 7, 9), ["--dtype", "fp64", "--step", "2", "--temporal", "1"]),
     ("2d_oddN_box25_stream", 2, "BOX25", (1, 23, 31), ["--dtype", "fp64", "--streaming", "--sn", "4", "--xrim", "lds"]),
+    ("3d_temporal2_prefetch_depth2", 3, "STAR3", (17, 21, 300), ["--3d", "--dtype", "fp64", "--sn", "6", "--step", "2", "--temporal", "1", "--prefetch", "--prefetch-depth", "2", "--by", "8", "--block-merge-y", "2"]),
 ]
 
 
@@ -129,6 +133,8 @@ RACE = [
     ("3d_step1_scatter_prefetch", 3, "STAR3", (15, 19, 300), ["--3d", "--dtype", "fp64", "--sn", "5", "--prefetch", "--xrim", "lds"]),
     ("2d_stream_temporal4", 2, "STAR2", (1, 40, 270), ["--dtype", "fp64", "--streaming", "--sn", "7", "--step", "4", "--temporal", "1", "--xrim", "lds"]),
     ("2d_tile_temporal3", 2, "BOX9", (1, 40, 140), ["--dtype", "fp64", "--step", "3", "--temporal", "1", "--xrim", "lds"]),
+    ("3d_step2_prefetch_depth2", 3, "STAR3", (23, 21, 300), ["--3d", "--dtype", "fp64", "--sn", "7", "--step", "2", "--prefetch", "--prefetch-depth", "2", "--xrim", "lds"]),
+    ("3d_temporal2_prefetch_depth2", 3, "STAR3", (17, 21, 300), ["--3d", "--dtype", "fp64", "--sn", "6", "--step", "2", "--temporal", "1", "--prefetch", "--prefetch-depth", "2", "--xrim", "lds", "--by", "8", "--block-merge-y", "2"]),
 ]
 
 
