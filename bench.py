@@ -64,9 +64,9 @@ TEMPORAL2 = {
 # N > 1 (z slabs of C4): the same fused kernel; slabs of 256 planes or fewer get 16-plane stream blocks -- too few
 # 32-plane blocks to keep 256 CUs evenly busy (256-plane view 0.394 ms vs 0.453 ms; 512-plane view 0.769 ms with 32
 # vs 0.808 ms with 16: profiles/r01_exp_r1y_slab_views.log, r01_exp_r1zc_slab_views_depth.log)
-def slab_options(workload, world):
+def slab_options(workload, world, weak=False):
     opts = list(TUNED[workload])
-    if workload == "c4" and world >= 4:
+    if workload == "c4" and world >= 4 and not weak:
         opts[opts.index("--sn") + 1] = "16"
     return opts
 
@@ -136,6 +136,8 @@ def main():
     ap.add_argument("--workload", default="c4", choices=sorted(WORKLOADS))
     ap.add_argument("--kernel-args", default=None, help="override the generator options (space separated)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--scaling", default="strong", choices=["strong", "weak"],
+                    help="N > 1: strong = the workload's grid cut into N slabs (default, SURVEY 8e); weak = every rank holds a full-size slab (grid L*N planes)")
     ap.add_argument("--headline-only", action="store_true", help="skip the side measurements (profiling runs: one dr_ kernel in the trace)")
     args = ap.parse_args()
 
@@ -148,10 +150,16 @@ def main():
     # Generate + compile (or find cached) every kernel BEFORE HIP is initialised: a process
     # that has touched the GPU must not fork/exec the compiler.
     w = WORKLOADS[args.workload]
-    opts = args.kernel_args.split() if args.kernel_args else (slab_options(args.workload, world) if world > 1 else TUNED[args.workload])
+    opts = args.kernel_args.split() if args.kernel_args else (slab_options(args.workload, world, args.scaling == "weak") if world > 1 else TUNED[args.workload])
     spec = drs.Spec(w["stc"], w["ndim"], int(opts[opts.index("--step") + 1]) if "--step" in opts else 1)
     L, M, N = spec.dims
     H, step, iters = spec.halo, spec.step, spec.iterations
+    weak = args.scaling == "weak" and world > 1
+    if weak:       # the outermost dim grows with the number of ranks: fixed work per GPU
+        if w["ndim"] == 3:
+            L *= world
+        else:
+            M *= world
     kern1 = kernf = None
     if world == 1:
         kern = drs.Kernel(opts + [w["stc"]])
@@ -241,7 +249,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         el, ev_ms = float(t[0]), float(t[1])
         kinfo = sweep.kernel(run.plan.interior[1] - run.plan.interior[0]).info
-        parallelism = "z-slab x%d, RCCL send/recv halo, overlapped" % world
+        parallelism = "%s-slab x%d%s, RCCL send/recv halo, overlapped" % ("z" if w["ndim"] == 3 else "y", world, " (weak: grid %s)" % "x".join(str(d) for d in ((L, M, N) if w["ndim"] == 3 else (M, N))) if weak else "")
         step1 = fused2 = None
 
     if rank == 0:
@@ -256,7 +264,7 @@ def main():
         out = {
             "metric": "GStencil/s (grid-point updates/s), 3d7pt_star" if args.workload in ("c3", "c4") else "GStencil/s (grid-point updates/s)",
             "value": value, "unit": "GStencil/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": el * 1e3 / args.steps, "higher_is_better": True, "scaling": "strong",
+            "ms_per_step": el * 1e3 / args.steps, "higher_is_better": True, "scaling": "weak" if weak else "strong",
             "vs_baseline": None, "dtype": "f32" if w["dtype"] == "fp32" else "f64", "data": "synthetic",
             "config": {"workload": w["name"], "generator_options": " ".join(opts), "step": step,
                        "launches_per_step": launches_per_step, "parallelism": parallelism,

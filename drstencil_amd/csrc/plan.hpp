@@ -60,7 +60,7 @@ struct GenOptions {
     int exact_y = -1;            // 1: halo loaders also fetch the source plane's y halo rows (every tile row owned);
                                  // 0: overlapped tiles; -1 auto: 1 for single-stage kernels, 0 for temporal pipelines
                                  // (measured: +3 % at step 1, -12 % on the 2-stage pipeline whose lanes own only 2 rows)
-    int debug_drop_barrier = 0;  // TIMING EXPERIMENTS ONLY: drop the barriers of stages >= 1 (results are wrong)
+    int debug_drop_barrier = 0;  // TIMING EXPERIMENTS ONLY: 1 drops the barriers of stages >= 1, 2 also the per-plane barrier of single-stage kernels (results are wrong)
     int clamp_loads = 1;         // branch-free loads (out-of-grid lanes read the plane origin) and uniform-guarded scalar stores
     int halo_spread = 0;         // spread the halo loader tasks over all wavefronts of the workgroup (no gain measured)
     int xedge_select = 0;        // --xrim dpp: wavefront-edge lanes take the LDS value by select instead of a branch
