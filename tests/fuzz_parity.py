@@ -35,6 +35,8 @@ def main():
                     i = cl.index("--dist"); cl[i + 1] = str(2 * v[0])
                 if ndim == 2 and random.random() < 0.5:
                     cl.append("--streaming")
+                if "--prefetch-depth" in cl:
+                    cl[cl.index("--prefetch-depth") + 1] = str(random.choice([1, 2, 3, 4]))
                 args = (["--3d"] if ndim == 3 else []) + ["--dtype", dtype] + cl + [stc]
                 jobs.append((ndim, stc, dtype, args, v[0]))
     t0 = time.time()
