@@ -13,6 +13,7 @@ rocprofv3 instead of Nsight Compute:
                   mergeForward, prefetch, xrim, temporal, xcd, streaming)
   * bx in {16,32,64,128,256}: lanes along x; mx in {1,2,4} points per lane (16-byte
     accesses at mx=4 fp32 / 2 fp64); by*my rows per tile; sn planes per stream block
+  * prefetch = planes of software prefetch in flight (0 off, True == 1; `p` / `p3` in the name)
   * LDS budget 160 KiB per CU (the reference caps at 32 KiB of A100 shared memory)
   * `duration` = average kernel duration in ns from HIP events over the reference's timed
     loop (10 warm-up launches first, codegen.hpp:575-584), i.e. what `ncu ... Duration` was

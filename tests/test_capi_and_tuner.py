@@ -77,6 +77,8 @@ def test_tuner_space_and_naming():
     assert t.cfgToCommandLine(v).startswith(" --bx 16 --by 8 --sn 8 --stream-unroll 4 --step 2 --dist 1 --cyclic-merge-x 1 --cyclic-merge-y 1 --merge-forward 5")
     vp = v[:10] + (True, "dpp", True, 0, False)
     assert t.cfgToString(vp).startswith("fu2d1bx16y8sn8u4cmx1cmy1mf5p")
+    v3 = v[:10] + (3, "dpp", False, 2, False)
+    assert t.cfgToString(v3) == "fu2d1bx16y8sn8u4cmx1cmy1mf5p3xdm2" and "--prefetch --prefetch-depth 3" in t.cfgToCommandLine(v3)
     space = t.enumerate_space((1, 2))
     assert len(space) > 100
     assert all(t.FilterParams(s) for s in space)
