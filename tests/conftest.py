@@ -34,15 +34,15 @@ def pytest_sessionstart(session):
     """GPU sessions: make sure every kernel the gpu tests use is built (normally a cache hit:
     __graft_entry__.build() prebuilds them) BEFORE anything initialises HIP -- a process that
     has touched the GPU must not fork/exec hipcc."""
+    import subprocess
+    import drstencil_amd as drs
+    if not os.path.exists(drs.LIB_PATH) or not os.path.exists(drs.CLI_PATH):
+        # a checkout without built artefacts: build the host code first (g++, seconds) -- CPU and GPU sessions alike
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "drstencil_amd", "csrc")], stdout=subprocess.DEVNULL)
     markexpr = session.config.getoption("-m") or ""
     if "gpu" not in markexpr or "not gpu" in markexpr:
         return
     sys.path.insert(0, os.path.join(ROOT, "tests"))
-    import subprocess
-    import drstencil_amd as drs
-    if not os.path.exists(drs.LIB_PATH) or not os.path.exists(drs.CLI_PATH):
-        # a checkout without built artefacts: build the host code first (g++, seconds)
-        subprocess.check_call(["make", "-C", os.path.join(ROOT, "drstencil_amd", "csrc")], stdout=subprocess.DEVNULL)
     from gpu_cases import all_build_args, golden_args
     from helpers import golden_cases, load_golden
     jobs = all_build_args()
