@@ -144,6 +144,14 @@ def main():
     import torch
     import drstencil_amd as drs
 
+    if not os.path.exists(drs.LIB_PATH):
+        # a checkout without built artefacts: build the host library (g++ only, seconds); ranks take turns on a lock
+        import fcntl
+        import subprocess
+        with open(os.path.join(ROOT, ".build.lock"), "w") as lk:
+            fcntl.flock(lk, fcntl.LOCK_EX)
+            if not os.path.exists(drs.LIB_PATH):
+                subprocess.check_call(["make", "-C", os.path.join(ROOT, "drstencil_amd", "csrc")], stdout=subprocess.DEVNULL)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
