@@ -155,29 +155,34 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # DRS_REHEARSE="r/R": run the N > 1 code path as middle rank r of R on ONE GPU (process group of size 1, the rank is
+    # its own neighbour) -- a rehearsal of the multi-GPU branch where only one GPU exists; the line says so
+    rehearse = os.environ.get("DRS_REHEARSE")
+    prank, pworld = (int(x) for x in rehearse.split("/")) if rehearse else (rank, world)
+    assert not rehearse or world == 1
     # Generate + compile (or find cached) every kernel BEFORE HIP is initialised: a process
     # that has touched the GPU must not fork/exec the compiler.
     w = WORKLOADS[args.workload]
-    opts = args.kernel_args.split() if args.kernel_args else (slab_options(args.workload, world, args.scaling == "weak") if world > 1 else TUNED[args.workload])
+    opts = args.kernel_args.split() if args.kernel_args else (slab_options(args.workload, pworld, args.scaling == "weak") if pworld > 1 else TUNED[args.workload])
     spec = drs.Spec(w["stc"], w["ndim"], int(opts[opts.index("--step") + 1]) if "--step" in opts else 1)
     L, M, N = spec.dims
     H, step, iters = spec.halo, spec.step, spec.iterations
-    weak = args.scaling == "weak" and world > 1
+    weak = args.scaling == "weak" and pworld > 1
     if weak:       # the outermost dim grows with the number of ranks: fixed work per GPU
         if w["ndim"] == 3:
-            L *= world
+            L *= pworld
         else:
-            M *= world
+            M *= pworld
     kern1 = kernf = None
-    if world == 1:
+    if pworld == 1:
         kern = drs.Kernel(opts + [w["stc"]])
         if args.workload in STEP1 and not args.kernel_args and not args.headline_only:
             kern1 = drs.Kernel(STEP1[args.workload] + [w["stc"]])
             kernf = drs.Kernel(TEMPORAL2[args.workload] + [w["stc"]])
     else:
-        from drstencil_amd.multigpu import HipSweep, SlabPlan, SlabRun
+        from drstencil_amd.multigpu import HipSweep, SelfNeighbourRun, SlabPlan, SlabRun
         sweep = HipSweep(w["stc"], opts, os.path.join(ROOT, "drstencil_amd", "_kcache"))
-        sp = SlabPlan(L if w["ndim"] == 3 else M, H, world, rank)
+        sp = SlabPlan(L if w["ndim"] == 3 else M, H, pworld, prank)
         for v in (sp.top, sp.bot, sp.interior):
             if v is not None and v[1] - v[0] > 2 * H:
                 sweep.kernel(v[1] - v[0])
@@ -186,9 +191,10 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
-    if world > 1:
+    if pworld > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29541")
         from drstencil_amd.multigpu import nccl_options
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev, pg_options=nccl_options(dist))
     assert world == args.gpus or world == 1 and args.gpus == 1, "launch with torch.distributed.run for --gpus > 1"
@@ -200,7 +206,7 @@ def main():
     npoints = M * N * (L if w["ndim"] == 3 else 1)
 
     ev_ms = 0.0
-    if world == 1:
+    if pworld == 1:
         g = torch.Generator(device=dev).manual_seed(1)
         shape = (L, M, N) if w["ndim"] == 3 else (M, N)
         A = torch.rand(shape, dtype=tdt, device=dev, generator=g)
@@ -233,8 +239,8 @@ def main():
         step1 = side(kern1, STEP1[args.workload], 16) if kern1 is not None else None
         fused2 = side(kernf, TEMPORAL2[args.workload], 32) if kernf is not None else None
     else:
-        run = SlabRun(torch, dist, (L, M, N) if w["ndim"] == 3 else (M, N), H, step, iters, rank, world, sweep, dev, tdt)
-        g = torch.Generator(device=dev).manual_seed(1 + rank)
+        run = (SelfNeighbourRun if rehearse else SlabRun)(torch, dist, (L, M, N) if w["ndim"] == 3 else (M, N), H, step, iters, prank, pworld, sweep, dev, tdt)
+        g = torch.Generator(device=dev).manual_seed(1 + prank)
         run.A.copy_(torch.rand(run.A.shape, dtype=tdt, device=dev, generator=g))
         for _ in range(args.warmup):
             run.run()
@@ -257,16 +263,19 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         el, ev_ms = float(t[0]), float(t[1])
         kinfo = sweep.kernel(run.plan.interior[1] - run.plan.interior[0]).info
-        parallelism = "%s-slab x%d%s, RCCL send/recv halo, overlapped" % ("z" if w["ndim"] == 3 else "y", world, " (weak: grid %s)" % "x".join(str(d) for d in ((L, M, N) if w["ndim"] == 3 else (M, N))) if weak else "")
+        parallelism = "%s-slab x%d%s, RCCL send/recv halo, overlapped" % ("z" if w["ndim"] == 3 else "y", pworld, " (weak: grid %s)" % "x".join(str(d) for d in ((L, M, N) if w["ndim"] == 3 else (M, N))) if weak else "")
         step1 = fused2 = None
 
     if rank == 0:
         total_launches = launches_per_step * args.steps
         updates = total_launches * step * interior
+        if rehearse:    # one rank's share of the work only: the other ranks do not exist
+            updates /= pworld
+            parallelism = "REHEARSAL on one GPU of rank %d of %d (self-neighbour exchange through RCCL): %s" % (prank, pworld, parallelism)
         value = updates / el / 1e9
         # roofline of the dominant kernel dr_<name>: algorithmic bytes per launch / average
         # launch duration from the HIP events around the timed launches
-        alg_bytes = 2.0 * esz * npoints / max(world, 1)     # per launch per GPU
+        alg_bytes = 2.0 * esz * npoints / max(pworld, 1)    # per launch per GPU
         avg_launch_s = (ev_ms * 1e-3) / total_launches
         achieved = alg_bytes / avg_launch_s / 1e9
         out = {
@@ -278,12 +287,12 @@ def main():
                        "launches_per_step": launches_per_step, "parallelism": parallelism,
                        "kernel": "dr_" + kinfo["name"], "threads": kinfo["threads"], "lds_bytes": kinfo["lds_bytes"]},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(args.workload, " ".join(opts)) if world == 1 else None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(args.workload, " ".join(opts)) if pworld == 1 else None,
                          "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": avg_launch_s * 1e3},
         }
         out["step1_kernel"] = step1                 # one time step per launch: highest roofline fraction
         out["temporal_step2_kernel"] = fused2       # on-chip temporal blocking (2 stages): equal to the headline up to rounding
-        if not args.no_cpu_baseline and world == 1:
+        if not args.no_cpu_baseline and pworld == 1:
             sys.path.insert(0, ROOT)
             out["cpu_baseline"] = cpu_baseline(args.workload, step)
         else:

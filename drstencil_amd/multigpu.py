@@ -91,7 +91,7 @@ def nccl_options(dist):
     """Process-group options for the slab run: RCCL's internal stream must not share an in-order hardware queue
     with the interior kernel's stream (it would run only after it), so it is created high priority."""
     o = dist.ProcessGroupNCCL.Options()
-    o.is_high_priority_stream = True
+    o.is_high_priority_stream = os.environ.get("DRS_RCCL_HIGH_PRIORITY", "1") != "0"   # 0: experiments only
     return o
 
 
@@ -207,3 +207,17 @@ class SlabRun:
         """The planes of `buf` this rank owns (global [z0, z1))."""
         p = self.plan
         return buf[p.z0 - p.lo:p.z1 - p.lo]
+
+
+class SelfNeighbourRun(SlabRun):
+    """Rehearsal of a middle rank on ONE GPU: both neighbours are this rank (what it sends "up" arrives in its lower
+    ghost planes and vice versa), through the same batch_isend_irecv calls on a real process group of size 1.  Used by
+    scripts/rccl_probe.py, bench.py's DRS_REHEARSE mode and the GPU tests; bytes move through RCCL's self-copy, not xGMI."""
+
+    def _exchange(self, dst):
+        p, dist = self.plan, self.dist
+        assert p.has_up and p.has_dn, "rehearse a middle rank"
+        ops = [dist.P2POp(dist.isend, dst[p.send_up[0]:p.send_up[1]], 0), dist.P2POp(dist.irecv, dst[p.recv_dn[0]:p.recv_dn[1]], 0),
+               dist.P2POp(dist.isend, dst[p.send_dn[0]:p.send_dn[1]], 0), dist.P2POp(dist.irecv, dst[p.recv_up[0]:p.recv_up[1]], 0)]
+        for w in dist.batch_isend_irecv(ops):
+            w.wait()

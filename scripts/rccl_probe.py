@@ -30,7 +30,7 @@ def main():
     a = ap.parse_args()
     import bench
     import drstencil_amd as drs
-    from drstencil_amd.multigpu import HipSweep, SlabPlan, SlabRun
+    from drstencil_amd.multigpu import HipSweep, SelfNeighbourRun, SlabPlan
     w = bench.WORKLOADS[a.workload]
     opts = bench.slab_options(a.workload, a.world)
     spec = drs.Spec(w["stc"], w["ndim"], 2)
@@ -51,17 +51,7 @@ def main():
     from drstencil_amd.multigpu import nccl_options
     dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev, pg_options=nccl_options(dist))
 
-    class SelfRun(SlabRun):
-        def _exchange(self, dst):
-            p = self.plan
-            ops = [dist.P2POp(dist.isend, dst[p.send_up[0]:p.send_up[1]], 0),
-                   dist.P2POp(dist.irecv, dst[p.recv_dn[0]:p.recv_dn[1]], 0),
-                   dist.P2POp(dist.isend, dst[p.send_dn[0]:p.send_dn[1]], 0),
-                   dist.P2POp(dist.irecv, dst[p.recv_up[0]:p.recv_up[1]], 0)]
-            for wk in dist.batch_isend_irecv(ops):
-                wk.wait()
-
-    run = SelfRun(torch, dist, (L, M, N), H, step, iters, frank, a.world, sweep, dev, torch.float32)
+    run = SelfNeighbourRun(torch, dist, (L, M, N), H, step, iters, frank, a.world, sweep, dev, torch.float32)
     g = torch.Generator(device=dev).manual_seed(1)
     run.A.copy_(torch.rand(run.A.shape, dtype=torch.float32, device=dev, generator=g))
     A0 = run.A.clone()

@@ -315,7 +315,7 @@ def test_rccl_exchange_choreography_on_one_gpu(torch_cuda, tmp_path):
     a missing event / wrong stream order shows up as stale ghost planes."""
     import torch.distributed as dist
     import drstencil_amd as drs
-    from drstencil_amd.multigpu import HipSweep, SlabRun, nccl_options
+    from drstencil_amd.multigpu import HipSweep, SelfNeighbourRun, SlabRun, nccl_options
     from gpu_cases import stc as stcp
     torch = torch_cuda
     opts = ["--3d", "--dtype", "fp32", "--step", "2", "--sn", "16"]
@@ -328,14 +328,6 @@ def test_rccl_exchange_choreography_on_one_gpu(torch_cuda, tmp_path):
     dist.init_process_group("nccl", store=dist.FileStore(str(tmp_path / "store"), 1), rank=0, world_size=1,
                             device_id=dev, pg_options=nccl_options(dist))
     try:
-        class SelfRccl(SlabRun):
-            def _exchange(self, dst):
-                p = self.plan
-                ops = [dist.P2POp(dist.isend, dst[p.send_up[0]:p.send_up[1]], 0), dist.P2POp(dist.irecv, dst[p.recv_dn[0]:p.recv_dn[1]], 0),
-                       dist.P2POp(dist.isend, dst[p.send_dn[0]:p.send_dn[1]], 0), dist.P2POp(dist.irecv, dst[p.recv_up[0]:p.recv_up[1]], 0)]
-                for wk in dist.batch_isend_irecv(ops):
-                    wk.wait()
-
         class SelfCopy(SlabRun):
             def _exchange(self, dst):
                 p = self.plan
@@ -344,7 +336,7 @@ def test_rccl_exchange_choreography_on_one_gpu(torch_cuda, tmp_path):
 
         A0 = torch.as_tensor(oracle.fill_random(spec.shape, np.float32))
         res = []
-        for cls in (SelfRccl, SelfCopy):
+        for cls in (SelfNeighbourRun, SelfCopy):
             run = cls(torch, dist, (L, M, N), H, 2, 24, 1, 3, sweep, dev, torch.float32)   # middle rank of 3
             run.load_global(lambda lo, hi: A0[lo:hi])
             n = run.run()
