@@ -138,6 +138,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--scaling", default="strong", choices=["strong", "weak"],
                     help="N > 1: strong = the workload's grid cut into N slabs (default, SURVEY 8e); weak = every rank holds a full-size slab (grid L*N planes)")
+    ap.add_argument("--exchange-every", type=int, default=0, choices=[0, 1, 2],
+                    help="N > 1: launches per halo exchange (2: ghost planes twice as wide, one exchange per ping-pong pair; "
+                         "0 = multigpu.choose_exchange_every)")
     ap.add_argument("--headline-only", action="store_true", help="skip the side measurements (profiling runs: one dr_ kernel in the trace)")
     args = ap.parse_args()
 
@@ -180,12 +183,13 @@ def main():
             kern1 = drs.Kernel(STEP1[args.workload] + [w["stc"]])
             kernf = drs.Kernel(TEMPORAL2[args.workload] + [w["stc"]])
     else:
-        from drstencil_amd.multigpu import HipSweep, SelfNeighbourRun, SlabPlan, SlabRun
+        from drstencil_amd.multigpu import HipSweep, SelfNeighbourRun, SlabPlan, SlabRun, choose_exchange_every
+        if args.exchange_every == 0:
+            cut = L if w["ndim"] == 3 else M
+            args.exchange_every = choose_exchange_every(cut // pworld, (M * N if w["ndim"] == 3 else N) * (4 if w["dtype"] == "fp32" else 8), H)
         sweep = HipSweep(w["stc"], opts, os.path.join(ROOT, "drstencil_amd", "_kcache"))
-        sp = SlabPlan(L if w["ndim"] == 3 else M, H, pworld, prank)
-        for v in (sp.top, sp.bot, sp.interior):
-            if v is not None and v[1] - v[0] > 2 * H:
-                sweep.kernel(v[1] - v[0])
+        for lv in SlabPlan(L if w["ndim"] == 3 else M, H, pworld, prank, args.exchange_every).views():
+            sweep.kernel(lv)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the product path has no CPU fallback)")
     torch.cuda.set_device(local_rank)
@@ -239,7 +243,7 @@ def main():
         step1 = side(kern1, STEP1[args.workload], 16) if kern1 is not None else None
         fused2 = side(kernf, TEMPORAL2[args.workload], 32) if kernf is not None else None
     else:
-        run = (SelfNeighbourRun if rehearse else SlabRun)(torch, dist, (L, M, N) if w["ndim"] == 3 else (M, N), H, step, iters, prank, pworld, sweep, dev, tdt)
+        run = (SelfNeighbourRun if rehearse else SlabRun)(torch, dist, (L, M, N) if w["ndim"] == 3 else (M, N), H, step, iters, prank, pworld, sweep, dev, tdt, every=args.exchange_every)
         g = torch.Generator(device=dev).manual_seed(1 + prank)
         run.A.copy_(torch.rand(run.A.shape, dtype=tdt, device=dev, generator=g))
         for _ in range(args.warmup):
@@ -263,7 +267,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         el, ev_ms = float(t[0]), float(t[1])
         kinfo = sweep.kernel(run.plan.interior[1] - run.plan.interior[0]).info
-        parallelism = "%s-slab x%d%s, RCCL send/recv halo, overlapped" % ("z" if w["ndim"] == 3 else "y", pworld, " (weak: grid %s)" % "x".join(str(d) for d in ((L, M, N) if w["ndim"] == 3 else (M, N))) if weak else "")
+        parallelism = "%s-slab x%d%s, RCCL send/recv halo every %d launch(es), overlapped" % ("z" if w["ndim"] == 3 else "y", pworld, " (weak: grid %s)" % "x".join(str(d) for d in ((L, M, N) if w["ndim"] == 3 else (M, N))) if weak else "", args.exchange_every)
         step1 = fused2 = None
 
     if rank == 0:

@@ -38,37 +38,66 @@ def slab_bounds(L, world, rank):
 
 
 class SlabPlan:
-    """Index bookkeeping for one rank (pure Python; unit-tested on CPU)."""
+    """Index bookkeeping for one rank (pure Python; unit-tested on CPU).
 
-    def __init__(self, L, H, world, rank):
-        self.L, self.H, self.world, self.rank = L, H, world, rank
+    every = 1: ghost width G = H, every launch is followed by an exchange of its output's H boundary planes.
+    every = 2: ghost width G = 2H and ONE exchange per ping-pong pair.  Launch 1 (A -> B) sweeps the whole local
+    slab with no exchange: it also computes the inner H planes of each ghost region, so B is valid on [H, Lloc-H).
+    Launch 2 (B -> A) produces exactly the owned planes and A's 2H boundary planes are exchanged: the same bytes per
+    pair of launches in half as many messages, with one boundary/interior split per pair instead of two, for 2H
+    redundantly computed planes per rank and pair (B's ghost planes are never exchanged or trusted)."""
+
+    def __init__(self, L, H, world, rank, every=1):
+        assert every in (1, 2)
+        self.L, self.H, self.world, self.rank, self.every = L, H, world, rank, every
+        G = self.G = every * H
         self.z0, self.z1 = slab_bounds(L, world, rank)
         self.has_up = rank > 0            # neighbour holding smaller z
         self.has_dn = rank < world - 1
-        self.lo = self.z0 - (H if self.has_up else 0)   # first global plane held locally
-        self.hi = self.z1 + (H if self.has_dn else 0)
+        self.lo = self.z0 - (G if self.has_up else 0)   # first global plane held locally
+        self.hi = self.z1 + (G if self.has_dn else 0)
         self.Lloc = self.hi - self.lo
-        if world > 1 and self.z1 - self.z0 < 2 * H:
-            raise ValueError("slab of %d planes is thinner than 2*halo=%d" % (self.z1 - self.z0, 2 * H))
-        # views (local plane ranges [a,b)) whose kernels write outputs [a+H, b-H)
-        self.top = (0, 3 * H) if self.has_up else None
-        self.bot = (self.Lloc - 3 * H, self.Lloc) if self.has_dn else None
-        a = H if self.has_up else 0
-        b = self.Lloc - (H if self.has_dn else 0)
+        if world > 1 and self.z1 - self.z0 < 2 * G:
+            raise ValueError("slab of %d planes is thinner than twice the ghost width %d" % (self.z1 - self.z0, G))
+        # views (local plane ranges [a,b)) whose kernels write outputs [a+H, b-H); those of the exchanging launch:
+        self.top = (G - H, 2 * G + H) if self.has_up else None                       # outputs = the planes sent up
+        self.bot = (self.Lloc - 2 * G - H, self.Lloc - G + H) if self.has_dn else None
+        a = 2 * G - H if self.has_up else 0
+        b = self.Lloc - 2 * G + H if self.has_dn else self.Lloc
         self.interior = (a, b)
-        # planes of dst to send / ghost planes to receive after a launch
-        self.send_up = (H, 2 * H) if self.has_up else None
-        self.recv_up = (0, H) if self.has_up else None
-        self.send_dn = (self.Lloc - 2 * H, self.Lloc - H) if self.has_dn else None
-        self.recv_dn = (self.Lloc - H, self.Lloc) if self.has_dn else None
+        # the launch without exchange (every = 2 only): the whole local slab
+        self.full = (0, self.Lloc)
+        # planes of dst to send / ghost planes to receive after an exchanging launch
+        self.send_up = (G, 2 * G) if self.has_up else None
+        self.recv_up = (0, G) if self.has_up else None
+        self.send_dn = (self.Lloc - 2 * G, self.Lloc - G) if self.has_dn else None
+        self.recv_dn = (self.Lloc - G, self.Lloc) if self.has_dn else None
+
+    def views(self):
+        """Every view length this rank launches a kernel on (for prebuilding)."""
+        out = [v[1] - v[0] for v in (self.top, self.bot, self.interior) if v is not None and v[1] - v[0] > 2 * self.H]
+        if self.every == 2 and self.world > 1:
+            out.append(self.Lloc)
+        return sorted(set(out))
 
     def outputs(self):
-        """Global output planes this rank writes per launch (for tests)."""
+        """Global output planes the exchanging launch writes on this rank (for tests)."""
         out = []
         for v in (self.top, self.interior, self.bot):
             if v is not None and v[1] - v[0] > 2 * self.H:
                 out.append((self.lo + v[0] + self.H, self.lo + v[1] - self.H))
         return out
+
+
+def choose_exchange_every(planes_per_rank, plane_bytes, H, link_GBps=60.0, kernel_GBps=5200.0):
+    """Launches per exchange for a slab run, from a two-number model (no multi-GPU box was available to measure it):
+    one exchange per ping-pong pair (every = 2) sends 2H planes per face and must hide under ONE interior sweep, so it
+    is chosen only when that sweep (2 * plane_bytes per plane at the slab kernels' ~5.2 TB/s) takes at least 1.3x the
+    transfer (one xGMI link, ~60 GB/s per direction through RCCL send/recv); otherwise every launch exchanges H planes.
+    C4 (4 MiB planes, H = 2): every = 2 up to 4 GPUs, 1 at 8."""
+    sweep_us = planes_per_rank * 2.0 * plane_bytes / (kernel_GBps * 1e3)
+    xfer_us = 2.0 * H * plane_bytes / (link_GBps * 1e3)
+    return 2 if planes_per_rank >= 8 * H and sweep_us >= 1.3 * xfer_us else 1
 
 
 def _write_view_stc(base_stc, ndim, L_view, cache_dir, tag):
@@ -122,11 +151,12 @@ class SlabRun:
     to a contiguous [Lv, M, N] view: outputs planes [H, Lv-H) of dst_view (HipSweep in the
     product; the CPU tests inject an oracle-backed callable to check the decomposition)."""
 
-    def __init__(self, torch, dist, dims, H, step, iterations, rank, world, sweep, device, dtype):
-        """dims = (L, M, N) for a 3D run cut along z, or (M, N) for a 2D run cut along y."""
+    def __init__(self, torch, dist, dims, H, step, iterations, rank, world, sweep, device, dtype, every=1):
+        """dims = (L, M, N) for a 3D run cut along z, or (M, N) for a 2D run cut along y; every = launches per
+        exchange (1 or 2, see SlabPlan)."""
         self.torch, self.dist = torch, dist
         dims = tuple(dims)
-        self.plan = SlabPlan(dims[0], H, world, rank)
+        self.plan = SlabPlan(dims[0], H, world, rank, every if world > 1 else 1)
         self.rest, self.H, self.step, self.iterations = dims[1:], H, step, iterations
         self.rank, self.world, self.sweep = rank, world, sweep
         self.device, self.dtype = device, dtype
@@ -192,12 +222,20 @@ class SlabRun:
                 self._exchange(dst)
         self.launch_count += 1
 
+    def launch_local(self, src, dst):
+        """One launch src -> dst over the whole local slab, no exchange (first launch of a pair, every = 2)."""
+        self.sweep(src, dst, self._stream_handle())
+        self.launch_count += 1
+
     def run(self, iterations=None):
         """The reference's ping-pong loop (codegen.hpp:581-584) on the slab; result in A."""
         it = self.iterations if iterations is None else iterations
         n, t = 0, 0
         while t < it:
-            self.launch(self.A, self.B)
+            if self.plan.every == 2:
+                self.launch_local(self.A, self.B)
+            else:
+                self.launch(self.A, self.B)
             self.launch(self.B, self.A)
             n += 2
             t += 2 * self.step

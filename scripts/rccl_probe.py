@@ -27,6 +27,7 @@ def main():
     ap.add_argument("--graph", action="store_true")
     ap.add_argument("--world", type=int, default=8)
     ap.add_argument("--workload", default="c4")
+    ap.add_argument("--every", type=int, default=2, help="launches per exchange (1 or 2)")
     a = ap.parse_args()
     import bench
     import drstencil_amd as drs
@@ -38,9 +39,8 @@ def main():
     H, step, iters = spec.halo, spec.step, spec.iterations
     sweep = HipSweep(w["stc"], opts, os.path.join(ROOT, "drstencil_amd", "_kcache"))
     frank = a.world // 2 - 1
-    sp = SlabPlan(L, H, a.world, frank)
-    for v in (sp.top, sp.bot, sp.interior):
-        sweep.kernel(v[1] - v[0])
+    for lv in SlabPlan(L, H, a.world, frank, a.every).views():
+        sweep.kernel(lv)
 
     import torch
     import torch.distributed as dist
@@ -51,7 +51,7 @@ def main():
     from drstencil_amd.multigpu import nccl_options
     dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev, pg_options=nccl_options(dist))
 
-    run = SelfNeighbourRun(torch, dist, (L, M, N), H, step, iters, frank, a.world, sweep, dev, torch.float32)
+    run = SelfNeighbourRun(torch, dist, (L, M, N), H, step, iters, frank, a.world, sweep, dev, torch.float32, every=a.every)
     g = torch.Generator(device=dev).manual_seed(1)
     run.A.copy_(torch.rand(run.A.shape, dtype=torch.float32, device=dev, generator=g))
     A0 = run.A.clone()

@@ -69,7 +69,6 @@ def pytest_sessionstart(session):
         sw = HipSweep(stcp("t3_star"), opts, SLAB_CACHE)
         drs.Kernel(opts + [stcp("t3_star")])
         for r in range(world):
-            sp = SlabPlan(70, halo, world, r)
-            for v in (sp.top, sp.bot, sp.interior):
-                if v is not None and v[1] - v[0] > 2 * halo:
-                    sw.kernel(v[1] - v[0])
+            for every in (1, 2):
+                for lv in SlabPlan(70, halo, world, r, every).views():
+                    sw.kernel(lv)

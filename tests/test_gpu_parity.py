@@ -264,12 +264,13 @@ class _FakeDist:
         return [self._Work() for _ in ops]
 
 
+@pytest.mark.parametrize("every", [1, 2], ids=["exchange_every_launch", "exchange_every_pair"])
 @pytest.mark.parametrize("world,opts", [
     (2, ["--3d", "--dtype", "fp32", "--sn", "8"]),
     (3, ["--3d", "--dtype", "fp32", "--step", "2", "--sn", "16"]),
     (2, ["--3d", "--dtype", "fp32", "--step", "2", "--temporal", "1", "--by", "8", "--block-merge-y", "4", "--sn", "16", "--prefetch"]),
 ], ids=["w2_step1", "w3_fused2", "w2_temporal2"])
-def test_slab_decomposition_on_one_gpu(torch_cuda, world, opts, tmp_path):
+def test_slab_decomposition_on_one_gpu(torch_cuda, world, opts, every, tmp_path):
     """z-slab decomposition (drstencil_amd.multigpu) with every rank on this GPU == the
     single-domain run of the same kernel, bit for bit."""
     import drstencil_amd as drs
@@ -287,14 +288,17 @@ def test_slab_decomposition_on_one_gpu(torch_cuda, world, opts, tmp_path):
     hub = _Hub()
     dev = torch.device("cuda", 0)
     sweep = HipSweep(stc, opts, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "drstencil_amd", "_kcache"))
-    runs = [SlabRun(torch, _FakeDist(hub, r), (L, M, N), H, step, spec.iterations, r, world, sweep, dev, torch.float32) for r in range(world)]
+    runs = [SlabRun(torch, _FakeDist(hub, r), (L, M, N), H, step, spec.iterations, r, world, sweep, dev, torch.float32, every=every) for r in range(world)]
     for r in runs:
         r.load_global(lambda lo, hi: A0[lo:hi])
     t, n = 0, 0
     while t < spec.iterations:
         for src, dst in (("A", "B"), ("B", "A")):
             for r in runs:
-                r.launch(getattr(r, src), getattr(r, dst))
+                if every == 2 and src == "A":
+                    r.launch_local(r.A, r.B)       # first launch of a pair: whole local slab, no exchange
+                else:
+                    r.launch(getattr(r, src), getattr(r, dst))
             torch.cuda.synchronize()
             hub.deliver()
             assert not hub.pending
@@ -307,7 +311,8 @@ def test_slab_decomposition_on_one_gpu(torch_cuda, world, opts, tmp_path):
         assert np.array_equal(r.owned(r.B).cpu().numpy(), B_ref[p.z0:p.z1]), "rank %d B" % r.rank
 
 
-def test_rccl_exchange_choreography_on_one_gpu(torch_cuda, tmp_path):
+@pytest.mark.parametrize("every", [1, 2], ids=["exchange_every_launch", "exchange_every_pair"])
+def test_rccl_exchange_choreography_on_one_gpu(torch_cuda, tmp_path, every):
     """The real RCCL transport under SlabRun's stream/event choreography, as far as one GPU can show it: this
     process is the only rank of an RCCL group and plays a middle rank whose two neighbours are itself (what it
     sends "up" arrives in its lower ghost planes and vice versa).  The run with batch_isend_irecv on RCCL's own
@@ -337,7 +342,7 @@ def test_rccl_exchange_choreography_on_one_gpu(torch_cuda, tmp_path):
         A0 = torch.as_tensor(oracle.fill_random(spec.shape, np.float32))
         res = []
         for cls in (SelfNeighbourRun, SelfCopy):
-            run = cls(torch, dist, (L, M, N), H, 2, 24, 1, 3, sweep, dev, torch.float32)   # middle rank of 3
+            run = cls(torch, dist, (L, M, N), H, 2, 24, 1, 3, sweep, dev, torch.float32, every=every)   # middle rank of 3
             run.load_global(lambda lo, hi: A0[lo:hi])
             n = run.run()
             torch.cuda.synchronize()
@@ -345,6 +350,6 @@ def test_rccl_exchange_choreography_on_one_gpu(torch_cuda, tmp_path):
             res.append((run.A.clone(), run.B.clone(), run.plan))
         (a1, b1, p), (a2, b2, _) = res
         assert torch.equal(a1, a2) and torch.equal(b1, b2)
-        assert bool((a1[p.recv_up[0]:p.recv_up[1]] != A0[p.lo:p.lo + H].to(dev)).any()), "ghost planes were never exchanged"
+        assert bool((a1[p.recv_up[0]:p.recv_up[1]] != A0[p.lo:p.lo + p.G].to(dev)).any()), "ghost planes were never exchanged"
     finally:
         dist.destroy_process_group()

@@ -13,7 +13,7 @@ import torch.distributed as dist
 import torch.multiprocessing as mp
 
 import oracle
-from drstencil_amd.multigpu import SlabPlan, SlabRun, slab_bounds
+from drstencil_amd.multigpu import SlabPlan, SlabRun, choose_exchange_every, slab_bounds
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 STC = os.path.join(ROOT, "tests", "stc", "smoke3.stc")   # 40 x 36 x 256, 3d7pt_star
@@ -36,6 +36,35 @@ def test_slab_plan_covers_every_interior_plane_once():
         SlabPlan(16, 3, 4, 1)
 
 
+def test_slab_plan_wide_ghosts_one_exchange_per_pair():
+    """every = 2: ghost width 2H; the exchanging launch writes exactly the owned planes, the launch before it the
+    whole local slab; what is sent are the first/last 2H owned planes."""
+    for L, H, R in [(40, 1, 2), (60, 2, 3), (1024, 2, 8), (1024, 1, 4)]:
+        seen = np.zeros(L, int)
+        for r in range(R):
+            p = SlabPlan(L, H, R, r, every=2)
+            G = 2 * H
+            assert p.G == G and p.lo == p.z0 - (G if p.has_up else 0) and p.hi == p.z1 + (G if p.has_dn else 0)
+            for a, b in p.outputs():
+                seen[a:b] += 1
+            outs = sorted(p.outputs())
+            assert outs[0][0] == max(p.z0, H) and outs[-1][1] == min(p.z1, L - H)
+            assert p.full == (0, p.Lloc) and p.Lloc in p.views()
+            if p.has_up:
+                assert p.send_up == (G, 2 * G) and p.recv_up == (0, G) and p.lo + p.send_up[0] == p.z0
+            if p.has_dn:
+                assert p.send_dn == (p.Lloc - 2 * G, p.Lloc - G) and p.lo + p.send_dn[1] == p.z1
+        assert np.all(seen[H:L - H] == 1) and not seen[:H].any() and not seen[L - H:].any()
+    with pytest.raises(ValueError):
+        SlabPlan(40, 3, 4, 1, every=2)
+
+
+def test_exchange_frequency_model():
+    # C4: 4 MiB planes, H = 2 -> one exchange per pair up to 4 GPUs (sweep of 256 planes >> transfer of 4 planes), every launch at 8
+    assert [choose_exchange_every(1024 // n, 4 << 20, 2) for n in (2, 4, 8)] == [2, 2, 1]
+    assert choose_exchange_every(12, 4 << 20, 2) == 1          # slab too thin for ghosts twice as wide
+
+
 def _free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -44,7 +73,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, step, iterations, q):
+def _worker(rank, world, port, step, iterations, every, q):
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -60,7 +89,7 @@ def _worker(rank, world, port, step, iterations, q):
         assert a.flags.c_contiguous and b.flags.c_contiguous
         oracle.sweep(vs, a, b, 1)
 
-    run = SlabRun(torch, dist, (L, M, N), H, step, iterations, rank, world, sweep, torch.device("cpu"), torch.float32)
+    run = SlabRun(torch, dist, (L, M, N), H, step, iterations, rank, world, sweep, torch.device("cpu"), torch.float32, every=every)
     full = oracle.fill_random((L, M, N), np.float32)
     run.load_global(lambda lo, hi: full[lo:hi])
     n = run.run()
@@ -69,12 +98,12 @@ def _worker(rank, world, port, step, iterations, q):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,step,iterations", [(2, 1, 4), (2, 2, 4), (3, 1, 5)])
-def test_slab_decomposition_matches_single_domain(world, step, iterations):
+@pytest.mark.parametrize("world,step,iterations,every", [(2, 1, 4, 1), (2, 2, 4, 1), (3, 1, 5, 1), (2, 2, 8, 2), (3, 1, 6, 2)])
+def test_slab_decomposition_matches_single_domain(world, step, iterations, every):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, step, iterations, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, step, iterations, every, q)) for r in range(world)]
     for p in procs:
         p.start()
     parts = [q.get(timeout=180) for _ in range(world)]
@@ -95,7 +124,7 @@ def test_slab_decomposition_matches_single_domain(world, step, iterations):
 STC2 = os.path.join(ROOT, "tests", "stc", "t2_box25.stc")   # 203 x 772, 2d25pt_box (halo 2)
 
 
-def _worker2d(rank, world, port, q):
+def _worker2d(rank, world, port, every, q):
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -108,7 +137,7 @@ def _worker2d(rank, world, port, q):
         vs.set_dims(1, src.shape[0], N)
         oracle.sweep(vs, src.numpy(), dst.numpy(), 1)
 
-    run = SlabRun(torch, dist, (M, N), spec.halo, 1, spec.iterations, rank, world, sweep, torch.device("cpu"), torch.float64)
+    run = SlabRun(torch, dist, (M, N), spec.halo, 1, spec.iterations, rank, world, sweep, torch.device("cpu"), torch.float64, every=every)
     full = oracle.fill_random((M, N), np.float64)
     run.load_global(lambda lo, hi: full[lo:hi])
     n = run.run()
@@ -117,12 +146,13 @@ def _worker2d(rank, world, port, q):
     dist.destroy_process_group()
 
 
-def test_2d_y_slab_decomposition_matches_single_domain():
+@pytest.mark.parametrize("every", [1, 2])
+def test_2d_y_slab_decomposition_matches_single_domain(every):
     world = 2
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker2d, args=(r, world, port, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker2d, args=(r, world, port, every, q)) for r in range(world)]
     for p in procs:
         p.start()
     parts = [q.get(timeout=180) for _ in range(world)]
