@@ -23,8 +23,11 @@ Three things measured with scripts/rccl_probe.py (profiles/r01_rccl_probe.md) sh
 Critical path per launch = boundary + max(interior, exchange).  Each neighbour pair talks over its own xGMI link;
 nothing is all-reduced in the loop.
 
+With `every = 2` (SlabPlan) the ghost planes are 2H wide and only every second launch -- the one that writes A --
+is followed by an exchange; the launch before it sweeps the whole local slab on the main stream.
+
 Kernels are ordinary generated kernels: a z sub-range of a slab is a contiguous view, so
-a "boundary kernel" is the generator's kernel for L = 3H planes and the interior kernel
+a "boundary kernel" is the generator's kernel for L = G + 2H planes (G = ghost width) and the interior kernel
 the one for the remaining view -- no special device code.
 """
 import os
