@@ -30,6 +30,52 @@ def _build_kernel(args):
         return "%s: %s" % (" ".join(args), str(e)[-300:])
 
 
+EMITTED_PROGRAMS = {
+    # id: (stencil file under tests/stc, generator options) -- the reference's process contract, SURVEY.md 8b:
+    # drstencil [options] --check -o <name>.hip <stc>; hipcc; run; read the program's stdout
+    "3d_step2_fp32": ("t3_star", ["--3d", "--dtype", "fp32", "--step", "2", "--check"]),
+    "2d_box25_fp64": ("t2_box25", ["--dtype", "fp64", "--check"]),
+    "2d_stream_fp32_step2": ("t2_star", ["--dtype", "fp32", "--streaming", "--step", "2", "--prefetch", "--check"]),
+}
+
+
+def _run_emitted_programs(drs, run_them=True):
+    """Generate, compile and RUN the standalone emitted programs in child processes, before this process touches
+    HIP (a process that has initialised the GPU must not start other programs); tests read the saved stdout."""
+    import shutil
+    import subprocess
+    out = os.path.join(ROOT, "drstencil_amd", "_kcache", "emitted_programs")
+    os.makedirs(out, exist_ok=True)
+    shutil.copy(os.path.join(drs.SUPPORT_DIR, "common.hpp"), out)
+    for pid, (stc, opts) in EMITTED_PROGRAMS.items():
+        src = os.path.join(ROOT, "tests", "stc", stc + ".stc")
+        log = os.path.join(out, pid + ".out")
+        try:
+            # the kernel name is the .stc path minus 4 characters (main.cpp:243-244): run from the spec's directory
+            hip, new = os.path.join(out, pid + ".hip"), os.path.join(out, pid + ".new.hip")
+            gen = subprocess.run([drs.CLI_PATH] + opts + ["-o", new, stc + ".stc"],
+                                 cwd=os.path.dirname(src), capture_output=True, text=True, timeout=60)
+            text = "[generator rc=%d]\n%s" % (gen.returncode, gen.stdout)
+            if gen.returncode == 0:
+                exe = os.path.join(out, pid)
+                body = lambda path: [ln for ln in open(path) if not ln.startswith(("// spec:", "// options:"))]   # banner holds paths
+                fresh = os.path.exists(exe) and os.path.exists(hip) and body(hip) == body(new)
+                os.replace(new, hip)
+                if fresh:       # same source as the binary that travelled with the tree (built by __graft_entry__.build())
+                    cc = subprocess.CompletedProcess([], 0, "", "")
+                else:
+                    cc = subprocess.run(["/opt/rocm/bin/hipcc", "-O3", "--offload-arch=gfx950", "-std=c++17", "-ffp-contract=off",
+                                         "-o", exe, hip], capture_output=True, text=True, timeout=300)
+                text += "[hipcc rc=%d]\n%s" % (cc.returncode, cc.stderr[-2000:])
+                if cc.returncode == 0 and run_them:
+                    run = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+                    text += "[program rc=%d]\n%s%s" % (run.returncode, run.stdout, run.stderr[-1000:])
+        except Exception as e:      # recorded, so that the test fails with the reason instead of the session
+            text = "[exception] %r" % (e,)
+        with open(log, "w") as f:
+            f.write(text)
+
+
 def pytest_sessionstart(session):
     """GPU sessions: make sure every kernel the gpu tests use is built (normally a cache hit:
     __graft_entry__.build() prebuilds them) BEFORE anything initialises HIP -- a process that
@@ -43,6 +89,7 @@ def pytest_sessionstart(session):
     if "gpu" not in markexpr or "not gpu" in markexpr:
         return
     sys.path.insert(0, os.path.join(ROOT, "tests"))
+    _run_emitted_programs(drs)
     from gpu_cases import all_build_args, golden_args
     from helpers import golden_cases, load_golden
     jobs = all_build_args()

@@ -211,6 +211,27 @@ def test_dpp_wave_shift_semantics(torch_cuda):
     assert torch.equal(o1, o2)
 
 
+@pytest.mark.parametrize("pid", ["3d_step2_fp32", "2d_box25_fp64", "2d_stream_fp32_step2"])
+def test_emitted_standalone_program(pid):
+    """The reference's process contract end to end: `drstencil ... --check -o x.hip spec.stc`, hipcc,
+    run the program, read its stdout protocol (codegen.hpp:554,573,588-589,595,621; common.hpp:99).  The three steps
+    ran in child processes at session start (tests/conftest.py); the optimised kernel must equal the gold kernel."""
+    import re
+    log = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "drstencil_amd", "_kcache", "emitted_programs", pid + ".out")
+    text = open(log).read()
+    assert "[generator rc=0]" in text and "[hipcc rc=0]" in text and "[program rc=0]" in text, text[-1500:]
+    body = text[text.index("[program rc=0]"):]
+    lines = [ln for ln in body.splitlines()[1:] if ln.strip()]
+    order = ["Initiating ...", "GPU computing ...", "GPU finished computing.", "GPU computation time:", "Checking error ...", "[Test] Max Error :", "[Test] RMS Error:"]
+    pos = [next(i for i, ln in enumerate(lines) if ln.startswith(tok)) for tok in order]
+    assert pos == sorted(pos), lines
+    assert not any("differ" in ln for ln in lines)                      # common.hpp:91-97 prints one line per new maximum
+    mx = float(re.search(r"\[Test\] Max Error : (\S+)", body).group(1))
+    rms = float(re.search(r"\[Test\] RMS Error: (\S+)", body).group(1))
+    assert mx == 1e-13 and rms == 0.0                                    # the reference's floor: no element differs
+    assert float(re.search(r"GPU computation time: (\S+) ms", body).group(1)) > 0
+
+
 def test_native_library_is_the_path():
     import drstencil_amd as drs
     assert drs.lib() is not None
