@@ -76,6 +76,26 @@ def _run_emitted_programs(drs, run_them=True):
             f.write(text)
 
 
+def _run_tuner_smoke():
+    """A six-configuration tuner search on a small grid, in a child process started before this process touches HIP
+    (the tuner builds with hipcc in its own worker pool and measures with HIP events): generate -> compile -> measure ->
+    results.jsonl + duration.log, the flow of the reference's benchmarks/<stencil>/tuning.py:102-142."""
+    import shutil
+    import subprocess
+    out = os.path.join(ROOT, "drstencil_amd", "_kcache", "tuner_smoke")
+    shutil.rmtree(out, ignore_errors=True)
+    os.makedirs(out, exist_ok=True)
+    try:
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "drstencil_amd", "tuner", "tuning.py"), os.path.join(ROOT, "tests", "stc", "t3_star.stc"),
+                            "--3d", "--dtype", "fp32", "--steps", "1,2", "--max-configs", "6", "--seed", "3", "--out", out],
+                           capture_output=True, text=True, timeout=600)
+        text = "[tuner rc=%d]\n%s%s" % (r.returncode, r.stdout[-4000:], r.stderr[-2000:])
+    except Exception as e:
+        text = "[exception] %r" % (e,)
+    with open(os.path.join(out, "stdout.txt"), "w") as f:
+        f.write(text)
+
+
 def pytest_sessionstart(session):
     """GPU sessions: make sure every kernel the gpu tests use is built (normally a cache hit:
     __graft_entry__.build() prebuilds them) BEFORE anything initialises HIP -- a process that
@@ -90,6 +110,7 @@ def pytest_sessionstart(session):
         return
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     _run_emitted_programs(drs)
+    _run_tuner_smoke()
     from gpu_cases import all_build_args, golden_args
     from helpers import golden_cases, load_golden
     jobs = all_build_args()

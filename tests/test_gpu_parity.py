@@ -232,6 +232,23 @@ def test_emitted_standalone_program(pid):
     assert float(re.search(r"GPU computation time: (\S+) ms", body).group(1)) > 0
 
 
+def test_tuner_search_end_to_end():
+    """The tuner ran a six-configuration search in a child process at session start
+    (tests/conftest.py): every configuration was generated, compiled and timed on this GPU, the results are sorted by
+    throughput and the best-so-far log only ever improves (duration.log of the reference's tuning.py:125-131)."""
+    import json
+    out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "drstencil_amd", "_kcache", "tuner_smoke")
+    text = open(os.path.join(out, "stdout.txt")).read()
+    assert "[tuner rc=0]" in text and "best:" in text, text[-1500:]
+    rows = [json.loads(ln) for ln in open(os.path.join(out, "results.jsonl"))]
+    timed = [r for r in rows if r.get("duration_ns")]
+    assert len(rows) == 6 and len(timed) >= 4, rows
+    for r in timed:
+        assert r["duration_ns"] > 0 and r["GStencil"] > 0 and 0 < r["frac"] < 1 and r["name"].startswith("fu")
+    best = [float(ln.split(",")[1]) for ln in open(os.path.join(out, "duration.log")) if ln.strip()]   # "<s> s, <ns>, <name>"
+    assert best and best == sorted(best, reverse=True)
+
+
 def test_native_library_is_the_path():
     import drstencil_amd as drs
     assert drs.lib() is not None
