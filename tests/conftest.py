@@ -96,6 +96,38 @@ def _run_tuner_smoke():
         f.write(text)
 
 
+def _run_reference_flow(drs):
+    """The reference's tuner <-> generator flow for ONE configuration (benchmarks/3d7pt_star/tuning.py:132-137,
+    compile_run.sh:1-5, getGpuMetrics.py:4-38) in child processes: ./drstencil --3d <cfg> --check -o ./cu/<name>.hip x.stc;
+    ./compile_run.sh <name> (hipcc, then the emitted program under rocprofv3: trace, FETCH_SIZE and WRITE_SIZE runs);
+    getGpuMetrics.py <name> -> gpuMetrics.csv + duration.log."""
+    import shutil
+    import subprocess
+    tdir = os.path.join(ROOT, "drstencil_amd", "tuner")
+    out = os.path.join(ROOT, "drstencil_amd", "_kcache", "reference_flow")
+    shutil.rmtree(out, ignore_errors=True)
+    os.makedirs(os.path.join(out, "cu"))
+    shutil.copy(os.path.join(drs.SUPPORT_DIR, "common.hpp"), os.path.join(out, "cu"))
+    shutil.copy(os.path.join(ROOT, "tests", "stc", "t3_star.stc"), out)
+    name = "fu2d2bx64y4sn16u4bmx4bmy2mf5pxdm2"
+    log = []
+    try:
+        env = dict(os.environ, TMPDIR="/tmp")
+        for cmd in ([drs.CLI_PATH, "--3d", "--dtype", "fp32", "--bx", "64", "--by", "4", "--sn", "16", "--stream-unroll", "4", "--step", "2", "--dist", "2",
+                     "--block-merge-x", "4", "--block-merge-y", "2", "--merge-forward", "5", "--prefetch", "--xrim", "dpp", "--xcd-remap", "2",
+                     "--check", "-o", "./cu/%s.hip" % name, "t3_star.stc"],
+                    ["bash", os.path.join(tdir, "compile_run.sh"), name],
+                    [sys.executable, os.path.join(tdir, "getGpuMetrics.py"), name]):
+            r = subprocess.run(cmd, cwd=out, env=env, capture_output=True, text=True, timeout=600)
+            log.append("[%s rc=%d]\n%s%s" % (os.path.basename(cmd[0] if cmd[0] != "bash" and cmd[0] != sys.executable else cmd[1]), r.returncode, r.stdout[-1500:], r.stderr[-1500:]))
+            if r.returncode != 0:
+                break
+    except Exception as e:
+        log.append("[exception] %r" % (e,))
+    with open(os.path.join(out, "flow.txt"), "w") as f:
+        f.write("\n".join(log))
+
+
 def pytest_sessionstart(session):
     """GPU sessions: make sure every kernel the gpu tests use is built (normally a cache hit:
     __graft_entry__.build() prebuilds them) BEFORE anything initialises HIP -- a process that
@@ -111,6 +143,7 @@ def pytest_sessionstart(session):
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     _run_emitted_programs(drs)
     _run_tuner_smoke()
+    _run_reference_flow(drs)
     from gpu_cases import all_build_args, golden_args
     from helpers import golden_cases, load_golden
     jobs = all_build_args()

@@ -249,6 +249,25 @@ def test_tuner_search_end_to_end():
     assert best and best == sorted(best, reverse=True)
 
 
+def test_reference_style_profile_flow():
+    """drstencil -> compile_run.sh (hipcc + the emitted program under rocprofv3, three runs) -> getGpuMetrics.py, run in
+    child processes at session start (tests/conftest.py): one gpuMetrics.csv row with the kernel's duration, the
+    FETCH_SIZE / WRITE_SIZE traffic and the program's own check result, and a duration.log line."""
+    import csv
+    out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "drstencil_amd", "_kcache", "reference_flow")
+    flow = open(os.path.join(out, "flow.txt")).read()
+    assert "[drstencil rc=0]" in flow and "[compile_run.sh rc=0]" in flow and "[getGpuMetrics.py rc=0]" in flow, flow[-2000:]
+    rows = list(csv.reader(open(os.path.join(out, "gpuMetrics.csv"))))
+    assert rows[0][0] == "Metric Name" and len(rows) == 3
+    rec = dict(zip(rows[0], rows[2]))
+    assert rec["Metric Name"].startswith("fu2d2bx64y4sn16") and float(rec["Duration"]) > 0 and int(rec["Calls"]) >= 12   # 10 warm-ups + the loop
+    alg, traffic = float(rec["Algorithmic Bytes"]), float(rec["HBM Traffic"])
+    # a 6.7 MB grid lives in the 256 MB Infinity Cache, so the HBM counters may read far below the algorithmic bytes
+    assert alg == 2 * 4 * 70 * 45 * 530 and 0 <= traffic < 3 * alg and float(rec["FETCH_SIZE"]) >= 0 and float(rec["WRITE_SIZE"]) >= 0
+    assert float(rec["RMS Error"]) == 0.0 and float(rec["Program Time"]) > 0
+    assert float(open(os.path.join(out, "duration.log")).read().split()[0]) == float(rec["Duration"])
+
+
 def test_native_library_is_the_path():
     import drstencil_amd as drs
     assert drs.lib() is not None
