@@ -79,8 +79,8 @@ MI355X options:
                         window: keep a rotating register window per resident plane.
 --temporal <0|1>        With --step n > 1: run the one-step stencil n times on chip (temporal blocking,
                         intermediate planes never leave the CU) instead of the fused stencil.
---prefetch-depth <n>    With --prefetch: planes in flight ahead of the one being summed (n+1 register sets; default 2 for
-                        fused multi-step 3D kernels, else 1).
+--prefetch-depth <n>    With --prefetch: planes in flight ahead of the one being summed (n+1 register sets; default 3 (fp32) /
+                        2 (fp64) for fused multi-step 3D kernels, else 1).
 --exact-y <0|1>         1 (default for single-stage kernels): the y halo rows of the source plane are fetched by the halo loader
                         lanes, so every tile row is owned; 0: overlapped tiles (tile rows include the halo).
 --clamp-loads <0|1>     1 (default): branch-free loads -- lanes outside the grid read the plane origin (their

@@ -67,7 +67,7 @@ struct GenOptions {
     int zgroup = 4;              // --xcd-remap 3: stream blocks of one tile taken by consecutive workgroups
     int prefetch_auto = 1;       // 3D kernels with step > 1 (fused or temporal) prefetch unless --prefetch-auto 0 (+28 % measured)
     int prefetch_depth = -1;     // planes in flight ahead of the one being summed (register sets = depth + 1); -1 auto:
-                                 // 2 for fused multi-step 3D kernels (their wide halo leaves one resident workgroup per CU and
+                                 // 3 (fp32) / 2 (fp64) for fused multi-step 3D kernels (their wide halo leaves one resident workgroup per CU and
                                  // too few bytes in flight: 1.66 -> 1.56 ms on a slow-memory device, +1 % on a fast one), else 1
     int temporal = 0;            // step > 1: apply the one-step stencil `step` times on chip instead of the fused stencil
     std::string schedule = "scatter";  // scatter: partial sums carried in VGPRs; window: rotating register windows

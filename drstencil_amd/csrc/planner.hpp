@@ -77,9 +77,11 @@ inline KernelPlan make_plan(const Stencil &st, const GenOptions &o_in, const std
         if (!o.sn_set) { o.sn = 32; o.sn_set = true; }
     }
     // Fused multi-step kernels in 3D (step > 1 without --temporal; tuned on 3d7pt_star 1024^3 step 2,
-    // profiles/r01_tune_c4_s2_exhaustive.txt): the wide fused window costs registers, so 2 rows per lane on
-    // 8 lane rows, longer stream blocks (the z halo is step*order planes) and software prefetch.
+    // profiles/r01_tune_c4_s2_exhaustive.txt, r01_tune_c3_s2_depth_exhaustive.txt): the wide fused window costs
+    // registers, so 2 rows per lane, 512 lanes (fp32: 32 x 16, the optimum of both searches; fp64: 64 x 8), longer
+    // stream blocks (the z halo is step*order planes) and software prefetch (depth: see HipEmitter::analyse).
     if (!o.ref_defaults && !o.temporal && st.step > 1 && st.ndim == 3) {
+        if (p.fp32 && !o.bx_set && !o.by_set) { o.bx = 32; o.by = 16; o.bx_set = o.by_set = true; }
         if (!o.by_set) { o.by = 8; o.by_set = true; }
         if (!o.my_set) { o.bmy = 2; o.cmy = 1; o.my_set = true; }
         if (!o.sn_set) { o.sn = 32; o.sn_set = true; }
