@@ -53,6 +53,8 @@ def lib():
     L.drs_kernel_info.argtypes = [vp]
     L.drs_kernel_path.restype = ctypes.c_char_p
     L.drs_kernel_path.argtypes = [vp]
+    L.drs_kernel_resources.restype = ctypes.c_char_p
+    L.drs_kernel_resources.argtypes = [vp]
     L.drs_kernel_launch.argtypes = [vp, vp, vp, vp]
     L.drs_kernel_launch_gold.argtypes = [vp, vp, vp, vp]
     L.drs_kernel_run.argtypes = [vp, vp, vp, ci, ci, vp]
@@ -71,7 +73,7 @@ EXPORTS = [
     "drs_version", "drs_free", "drs_generate",
     "drs_spec_open", "drs_spec_close", "drs_spec_halo", "drs_spec_dist", "drs_spec_range", "drs_spec_npoints",
     "drs_spec_iterations", "drs_spec_launches", "drs_spec_dims", "drs_spec_point", "drs_spec_partition",
-    "drs_kernel_build", "drs_kernel_close", "drs_kernel_info", "drs_kernel_path", "drs_kernel_launch",
+    "drs_kernel_build", "drs_kernel_close", "drs_kernel_info", "drs_kernel_path", "drs_kernel_resources", "drs_kernel_launch",
     "drs_kernel_launch_gold", "drs_kernel_run", "drs_kernel_run_timed",
     "drs_fill_random_f64", "drs_fill_random_f32", "drs_check_error_f64", "drs_check_error_f32",
 ]
@@ -172,6 +174,7 @@ class Kernel:
             raise KernelBuildError(msg or "kernel build failed")
         self.info = json.loads(lib().drs_kernel_info(self.h).decode())
         self.path = lib().drs_kernel_path(self.h).decode()
+        self.resources = json.loads(lib().drs_kernel_resources(self.h).decode() or "{}")   # registers / scratch / LDS per the compiler
         self.args = list(args)
 
     def launch(self, d_in, d_out, stream=0):

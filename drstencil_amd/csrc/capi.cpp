@@ -31,6 +31,7 @@ struct drs_kernel {
     int (*launch_gold)(const void *, void *, hipStream_t) = nullptr;
     const char *(*info)(void) = nullptr;
     std::string path;
+    std::string resources;   // JSON: register / scratch / LDS use of dr_<name> as reported by the compiler
     int step = 1;
 };
 
@@ -155,6 +156,39 @@ static std::string run_capture(const std::string &cmd, int *rc) {
     return out;
 }
 
+// "<label>: <number>" inside the compiler's resource-usage remark block of one function
+static long remark_value(const std::string &block, const char *label) {
+    size_t at = block.find(label);
+    if (at == std::string::npos) return -1;
+    at = block.find(':', at + strlen(label) - 1);
+    return at == std::string::npos ? -1 : strtol(block.c_str() + at + 1, nullptr, 10);
+}
+
+// Resource use of dr_<name> from hipcc's -Rpass-analysis=kernel-resource-usage remarks, as JSON.
+static std::string resources_json(const std::string &hipcc_output, const std::string &kernel) {
+    size_t at = hipcc_output.find("Function Name: dr_" + kernel);
+    if (at == std::string::npos) return "{}";
+    size_t end = hipcc_output.find("Function Name:", at + 14);
+    const std::string b = hipcc_output.substr(at, end == std::string::npos ? std::string::npos : end - at);
+    char buf[512];
+    snprintf(buf, sizeof buf, "{\"vgprs\": %ld, \"agprs\": %ld, \"sgprs\": %ld, \"scratch_bytes_per_lane\": %ld, \"sgpr_spill\": %ld, "
+                              "\"vgpr_spill\": %ld, \"occupancy_waves_per_simd\": %ld, \"lds_bytes\": %ld}",
+             remark_value(b, "VGPRs:"), remark_value(b, "AGPRs:"), remark_value(b, "TotalSGPRs:"), remark_value(b, "ScratchSize [bytes/lane]:"),
+             remark_value(b, "SGPRs Spill:"), remark_value(b, "VGPRs Spill:"), remark_value(b, "Occupancy [waves/SIMD]:"), remark_value(b, "LDS Size [bytes/block]:"));
+    return buf;
+}
+
+static std::string read_text(const std::string &path) {
+    std::string out;
+    FILE *f = fopen(path.c_str(), "r");
+    if (!f) return out;
+    char buf[4096];
+    size_t n;
+    while ((n = fread(buf, 1, sizeof buf, f)) > 0) out.append(buf, n);
+    fclose(f);
+    return out;
+}
+
 drs_kernel *drs_kernel_build(int argc, const char *const *argv, const char *cache_dir, char **log) {
     if (log) *log = nullptr;
     GenResult r = generate(to_args(argc, argv));
@@ -168,13 +202,14 @@ drs_kernel *drs_kernel_build(int argc, const char *const *argv, const char *cach
     mkdir(cdir.c_str(), 0777);
     const char *hipcc_env = getenv("DRS_HIPCC");
     const std::string hipcc = hipcc_env ? hipcc_env : "/opt/rocm/bin/hipcc";
-    const std::string flags = "-O3 --offload-arch=gfx950 -std=c++17 -ffp-contract=off -shared -fPIC -DDRS_PLUGIN";
+    // the resource-usage remarks (registers, scratch, LDS per kernel) only add diagnostics; they are parsed below
+    const std::string flags = "-O3 --offload-arch=gfx950 -std=c++17 -ffp-contract=off -shared -fPIC -DDRS_PLUGIN -Rpass-analysis=kernel-resource-usage";
     // the key covers everything that determines the binary except the banner lines
     std::string body = r.source.substr(r.source.find("#include"));
     char key[64];
     snprintf(key, sizeof key, "%s_%016llx", r.plan.name.c_str(), fnv1a(body + flags));
-    const std::string src = cdir + "/" + key + ".hip", so = cdir + "/" + key + ".so";
-    if (!file_exists(so)) {
+    const std::string src = cdir + "/" + key + ".hip", so = cdir + "/" + key + ".so", res = cdir + "/" + key + ".res";
+    if (!file_exists(so) || !file_exists(res)) {
         char tmpl[64];
         snprintf(tmpl, sizeof tmpl, ".%d.tmp", (int)getpid());
         const std::string tsrc = src + tmpl + ".hip", tso = so + tmpl;
@@ -186,8 +221,22 @@ drs_kernel *drs_kernel_build(int argc, const char *const *argv, const char *cach
             unlink(tso.c_str());
             return nullptr;
         }
+        const std::string tres = res + tmpl;
+        if (!write_text(tres, resources_json(out, r.plan.name) + "\n")) { if (log) *log = dup_cstr("cannot write " + tres + "\n"); return nullptr; }
         rename(tsrc.c_str(), src.c_str());
+        rename(tres.c_str(), res.c_str());
         rename(tso.c_str(), so.c_str());
+    }
+    // A kernel that spills to scratch has outgrown the 512 registers a lane can have: it is slow, and it is where the
+    // two miscompiled kernels of the round-1 parity fuzz came from (profiles/r01_fuzz_parity_1200.txt), so it is refused.
+    const std::string resources = read_text(res);
+    const long scratch = remark_value(resources, "\"scratch_bytes_per_lane\":");
+    const char *allow = getenv("DRS_ALLOW_SCRATCH");
+    if (scratch > 0 && !(allow && allow[0] == '1')) {
+        if (log) *log = dup_cstr("drstencil: kernel dr_" + r.plan.name + " spills " + std::to_string(scratch) + " bytes per lane to scratch memory " + resources +
+                                 "-- the configuration exceeds the register file: use a smaller tile (--by, --block-merge-y), --prefetch-depth 1 or a "
+                                 "256-lane workgroup (DRS_ALLOW_SCRATCH=1 loads it anyway)\n");
+        return nullptr;
     }
     void *dl = dlopen(so.c_str(), RTLD_NOW | RTLD_LOCAL);
     if (!dl) { if (log) *log = dup_cstr(std::string("dlopen failed: ") + dlerror() + "\n"); return nullptr; }
@@ -197,6 +246,7 @@ drs_kernel *drs_kernel_build(int argc, const char *const *argv, const char *cach
     k->launch_gold = (int (*)(const void *, void *, hipStream_t))dlsym(dl, "drs_plugin_launch_gold");
     k->info = (const char *(*)(void))dlsym(dl, "drs_plugin_info");
     k->path = so;
+    k->resources = resources;
     k->step = r.st.step;
     if (!k->launch || !k->launch_gold || !k->info) {
         if (log) *log = dup_cstr("plugin " + so + " lacks the drs_plugin_* entry points\n");
@@ -214,6 +264,7 @@ void drs_kernel_close(drs_kernel *k) {
 }
 const char *drs_kernel_info(const drs_kernel *k) { return k->info(); }
 const char *drs_kernel_path(const drs_kernel *k) { return k->path.c_str(); }
+const char *drs_kernel_resources(const drs_kernel *k) { return k->resources.c_str(); }
 
 int drs_kernel_launch(drs_kernel *k, const void *d_in, void *d_out, void *stream) {
     return k->launch(d_in, d_out, (hipStream_t)stream);

@@ -81,6 +81,11 @@ inline KernelPlan make_plan(const Stencil &st, const GenOptions &o_in, const std
     // registers, so 2 rows per lane, 512 lanes (fp32: 32 x 16, the optimum of both searches; fp64: 64 x 8), longer
     // stream blocks (the z halo is step*order planes) and software prefetch (depth: see HipEmitter::analyse).
     if (!o.ref_defaults && !o.temporal && st.step > 1 && st.ndim == 3) {
+        // beyond the 25-point fused 7-point star (63-point step 3, 27-point fused cross, ...) the partial sums and rims of
+        // a 512-lane workgroup no longer fit 256 registers per lane and spill to scratch: 256 lanes (64 x 4) may use the
+        // AGPR half of the register file as well and stay spill-free
+        const bool heavy = st.pts.size() > 25;
+        if (heavy && !o.bx_set && !o.by_set) { o.bx = 64; o.by = 4; o.bx_set = o.by_set = true; }
         if (p.fp32 && !o.bx_set && !o.by_set) { o.bx = 32; o.by = 16; o.bx_set = o.by_set = true; }
         if (!o.by_set) { o.by = 8; o.by_set = true; }
         if (!o.my_set) { o.bmy = 2; o.cmy = 1; o.my_set = true; }

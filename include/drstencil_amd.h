@@ -53,6 +53,10 @@ drs_kernel *drs_kernel_build(int argc, const char *const *argv, const char *cach
 void drs_kernel_close(drs_kernel *k);
 const char *drs_kernel_info(const drs_kernel *k);   /* JSON: dims, dtype, halo, step, grid, lds ... */
 const char *drs_kernel_path(const drs_kernel *k);   /* the loaded shared object */
+/* JSON: vgprs, agprs, sgprs, scratch_bytes_per_lane, sgpr_spill, vgpr_spill, occupancy_waves_per_simd, lds_bytes of
+ * dr_<name> as reported by hipcc (what the reference reads from `ncu --set full`, getGpuMetrics.py:9).  A kernel that
+ * spills to scratch is refused by drs_kernel_build (NULL + log) unless DRS_ALLOW_SCRATCH=1. */
+const char *drs_kernel_resources(const drs_kernel *k);
 /* one launch of dr_<name><<<grid, block, 0, stream>>>(in, out): codegen.hpp:577,582-583 */
 int drs_kernel_launch(drs_kernel *k, const void *d_in, void *d_out, void *stream);
 /* one launch of gold_<name> (the reference's verification kernel, codegen.hpp:611-612) */

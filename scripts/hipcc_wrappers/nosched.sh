@@ -1,0 +1,2 @@
+#!/bin/bash
+exec /opt/rocm/bin/hipcc "$@" -mllvm -enable-misched=0 -mllvm -enable-post-misched=0

@@ -18,7 +18,7 @@ def build(job):
     try:
         drs.Kernel(job[3]); return None
     except Exception as e:
-        return "%s: %s" % (" ".join(job[3]), str(e).strip().splitlines()[-1][:200])
+        return "%s: %s" % (" ".join(job[3]), " ".join(str(e).split())[:260])
 
 def main():
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 120
@@ -44,7 +44,8 @@ def main():
         errs = list(ex.map(build, jobs))
     ok_jobs = [j for j, e in zip(jobs, errs) if e is None]
     rejected = [e for e in errs if e is not None]
-    print("built %d kernels in %.0f s; %d configurations rejected by the generator" % (len(ok_jobs), time.time() - t0, len(rejected)), flush=True)
+    print("built %d kernels in %.0f s; %d configurations rejected by the generator or refused by the runtime (%d for scratch spills)"
+          % (len(ok_jobs), time.time() - t0, len(rejected), sum(1 for e in rejected if "scratch" in e)), flush=True)
     for e in rejected[:5]:
         print("  rejected:", e)
     kerns = [(j, drs.Kernel(j[3])) for j in ok_jobs]

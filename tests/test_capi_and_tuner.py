@@ -2,6 +2,7 @@
 without a GPU), host helpers, and the tuner's space/naming logic."""
 import ctypes
 import os
+import sys
 import re
 
 import numpy as np
@@ -66,6 +67,31 @@ def test_kernel_info_and_work_model():
     assert k.updates_per_launch() == 38 * 34 * 254
     assert k.bytes_per_launch() == 2 * 4 * 40 * 36 * 256
     assert os.path.exists(k.path) and k.path.endswith(".so")
+
+
+def test_kernel_resources_and_scratch_refusal(monkeypatch):
+    """The runtime reads the compiler's resource report for every kernel it builds and refuses one that spills to
+    scratch (it has outgrown the register file: slow, and the only place the round-1 parity fuzz found miscompiled
+    kernels); the automatic geometry for the same heavy stencil fits and loads."""
+    stc = os.path.join(ROOT, "tests", "stc", "t3_star.stc")
+    k = drs.Kernel(["--3d", "--dtype", "fp32", "--step", "3", stc])                      # 63-point fused stencil, automatic geometry
+    assert k.info["threads"] == 256 and k.resources["scratch_bytes_per_lane"] == 0 and k.resources["vgprs"] > 0
+    spilling = ["--3d", "--dtype", "fp32", "--step", "3", "--bx", "32", "--by", "16", "--block-merge-y", "2", "--prefetch-depth", "3", stc]
+    monkeypatch.delenv("DRS_ALLOW_SCRATCH", raising=False)
+    with pytest.raises(RuntimeError) as e:
+        drs.Kernel(spilling)
+    assert "spills" in str(e.value) and "scratch" in str(e.value)
+    monkeypatch.setenv("DRS_ALLOW_SCRATCH", "1")
+    k2 = drs.Kernel(spilling)
+    assert k2.resources["scratch_bytes_per_lane"] > 0
+
+
+def test_bench_headline_kernel_is_a_full_size_parity_case():
+    import bench
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import gpu_cases
+    head = [c for c in gpu_cases.FULL if "bench_headline" in c[0]]
+    assert head and head[0][3] == bench.TUNED["c4"] and head[0][2] == bench.WORKLOADS["c4"]["stc"]
 
 
 def test_tuner_space_and_naming():
