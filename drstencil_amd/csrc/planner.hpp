@@ -85,7 +85,11 @@ inline KernelPlan make_plan(const Stencil &st, const GenOptions &o_in, const std
         // a 512-lane workgroup no longer fit 256 registers per lane and spill to scratch: 256 lanes (64 x 4) may use the
         // AGPR half of the register file as well and stay spill-free
         const bool heavy = st.pts.size() > 25;
-        if (heavy && !o.bx_set && !o.by_set) { o.bx = 64; o.by = 4; o.bx_set = o.by_set = true; }
+        if (heavy && !o.bx_set && !o.by_set) {
+            if (p.fp32) { o.bx = 64; o.by = 4; }
+            else { o.bx = 32; o.by = 8; if (!o.my_set) { o.bmy = 1; o.cmy = 1; o.my_set = true; } }   // fp64: one row per lane (2 rows spill at 512^3)
+            o.bx_set = o.by_set = true;
+        }
         if (p.fp32 && !o.bx_set && !o.by_set) { o.bx = 32; o.by = 16; o.bx_set = o.by_set = true; }
         if (!o.by_set) { o.by = 8; o.by_set = true; }
         if (!o.my_set) { o.bmy = 2; o.cmy = 1; o.my_set = true; }
