@@ -17,7 +17,8 @@ support=${DRS_SUPPORT:-$here/../csrc/support}
 mkdir -p bin prof
 src=cu/${name}.hip
 [ -f "$src" ] || src=cu/${name}.cu      # the reference's tuner writes cu/<name>.cu; hipcc compiles it as HIP
-hipcc -x hip ${src} -O3 --offload-arch=${ARCH} -std=c++17 -ffp-contract=off -I${support} -I cu -o bin/${name}
+# the compiler's per-kernel resource report (registers, scratch, spills) goes to prof/<name>.resources.txt
+hipcc -x hip ${src} -O3 --offload-arch=${ARCH} -std=c++17 -ffp-contract=off -Rpass-analysis=kernel-resource-usage -I${support} -I cu -o bin/${name} 2> prof/${name}.resources.txt || { cat prof/${name}.resources.txt >&2; exit 1; }
 cd /tmp 2>/dev/null && export TMPDIR=/tmp && cd - > /dev/null
 rocprofv3 --kernel-trace --stats --output-format csv -d prof/${name}/trace -- bin/${name} > prof/${name}.log 2>&1
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --kernel-include-regex "${regex}" --output-format csv -d prof/${name}/fetch -- bin/${name} > /dev/null 2>&1

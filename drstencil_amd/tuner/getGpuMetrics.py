@@ -13,8 +13,8 @@ import re
 import sys
 
 HEADER = ["Metric Name", "Duration", "Calls", "FETCH_SIZE", "WRITE_SIZE", "HBM Traffic", "Algorithmic Bytes", "Achieved Bandwidth",
-          "Roofline Fraction", "GStencil/s", "Grid Size", "Block Size", "LDS Per Block", "VGPR", "SGPR", "Program Time", "RMS Error"]
-UNITS = ["", "nsecond", "", "KiB", "KiB", "byte", "byte", "GB/s", "of 8 TB/s", "", "", "", "byte", "", "", "ms", ""]
+          "Roofline Fraction", "GStencil/s", "Grid Size", "Block Size", "LDS Per Block", "VGPR", "SGPR", "Program Time", "RMS Error", "AGPR", "Scratch", "VGPR Spill"]
+UNITS = ["", "nsecond", "", "KiB", "KiB", "byte", "byte", "GB/s", "of 8 TB/s", "", "", "", "byte", "", "", "ms", "", "", "byte/lane", ""]
 
 
 def _one(pattern):
@@ -57,9 +57,16 @@ def main(name=""):
     log = open(base + ".log").read() if os.path.exists(base + ".log") else ""
     t = re.search(r"GPU computation time: ([0-9.]+) ms", log)
     rms = re.search(r"\[Test\] RMS Error: (\S+)", log)
+    # the compiler's resource report of the dr_ kernel (compile_run.sh keeps it)
+    rep = open(base + ".resources.txt").read() if os.path.exists(base + ".resources.txt") else ""
+    at = rep.find("Function Name: dr_")
+    rep = rep[at:rep.find("Function Name:", at + 14) if at >= 0 and rep.find("Function Name:", at + 14) > 0 else None] if at >= 0 else ""
+    def _rep(label):
+        m = re.search(re.escape(label) + r"\s*(\d+)", rep)
+        return m.group(1) if m else ""
     row = [name, dur, calls, fetch, write, traffic, alg, gbs, gbs / 8000.0, interior * mac.get("Step", 1) / dur if dur == dur and dur > 0 else float("nan"),
            meta.get("Grid_Size", ""), meta.get("Workgroup_Size", ""), meta.get("LDS_Block_Size", ""), meta.get("VGPR_Count", ""), meta.get("SGPR_Count", ""),
-           t.group(1) if t else "", rms.group(1) if rms else ""]
+           t.group(1) if t else "", rms.group(1) if rms else "", _rep("AGPRs:"), _rep("ScratchSize [bytes/lane]:"), _rep("VGPRs Spill:")]
     new = not os.path.exists("gpuMetrics.csv")
     with open("gpuMetrics.csv", "a", newline="") as f:
         w = csv.writer(f, quoting=csv.QUOTE_ALL)

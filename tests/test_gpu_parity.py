@@ -265,6 +265,7 @@ def test_reference_style_profile_flow():
     # a 6.7 MB grid lives in the 256 MB Infinity Cache, so the HBM counters may read far below the algorithmic bytes
     assert alg == 2 * 4 * 70 * 45 * 530 and 0 <= traffic < 3 * alg and float(rec["FETCH_SIZE"]) >= 0 and float(rec["WRITE_SIZE"]) >= 0
     assert float(rec["RMS Error"]) == 0.0 and float(rec["Program Time"]) > 0
+    assert rec["Scratch"] == "0" and rec["VGPR Spill"] == "0" and int(rec["AGPR"]) >= 0          # the compiler's resource report
     assert float(open(os.path.join(out, "duration.log")).read().split()[0]) == float(rec["Duration"])
 
 
