@@ -151,7 +151,8 @@ def pytest_sessionstart(session):
         meta, *_ = load_golden(c)
         opts, stc = golden_args(c, meta)
         jobs.append(opts + [stc])
-    from gpu_cases import stc as stcp
+    from gpu_cases import stc as stcp, fuzz_sample_jobs
+    fuzz_args = [j[3] for j in fuzz_sample_jobs()]     # some of these are refused (scratch spills): not an error
     jobs.append(["--dtype", "fp32", "--streaming", "--xrim", "lds", stcp("t2_box25")])
     jobs.append(["--dtype", "fp32", "--streaming", "--xrim", "dpp", stcp("t2_box25")])
     # cache hits return at once; misses are compiled in parallel worker processes (hipcc), all of it
@@ -159,6 +160,7 @@ def pytest_sessionstart(session):
     from concurrent.futures import ProcessPoolExecutor
     with ProcessPoolExecutor(max_workers=min(16, os.cpu_count() or 1)) as ex:
         bad = [r for r in ex.map(_build_kernel, jobs) if r]
+        list(ex.map(_build_kernel, fuzz_args))
     assert not bad, "kernel builds failed:\n" + "\n".join(bad)
     # slab-view kernels of test_slab_decomposition_on_one_gpu (compiled here, before HIP is up)
     import tempfile

@@ -20,9 +20,9 @@ def build(job):
     except Exception as e:
         return "%s: %s" % (" ".join(job[3]), " ".join(str(e).split())[:260])
 
-def main():
-    n = int(sys.argv[1]) if len(sys.argv) > 1 else 120
-    random.seed(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+def make_jobs(n, seed):
+    """n random configurations (tuner space x test stencils x dtypes): (ndim, stc, dtype, drstencil args, step)."""
+    random.seed(seed)
     jobs = []
     for ndim, name, order in STCS:
         stc = os.path.join(ROOT, "tests", "stc", name + ".stc")
@@ -39,6 +39,32 @@ def main():
                     cl[cl.index("--prefetch-depth") + 1] = str(random.choice([1, 2, 3, 4]))
                 args = (["--3d"] if ndim == 3 else []) + ["--dtype", dtype] + cl + [stc]
                 jobs.append((ndim, stc, dtype, args, v[0]))
+    return jobs
+
+
+def check(job, k, torch):
+    """One configuration on the GPU against the oracle: (good, temporal, max relative error)."""
+    ndim, stc, dtype, args, step = job
+    temporal = k.info.get("stages", 1) > 1
+    spec = oracle.Spec(stc, ndim, step)
+    A0 = oracle.fill_random(spec.shape, np.float32 if dtype == "fp32" else np.float64)
+    Ar, Br = A0.copy(), np.zeros_like(A0)
+    oracle.run(spec, Ar, Br, contract=1)
+    dA = torch.from_numpy(A0).cuda(); dB = torch.zeros_like(dA)
+    k.run(dA.data_ptr(), dB.data_ptr())
+    torch.cuda.synchronize()
+    A, B = dA.cpu().numpy(), dB.cpu().numpy()
+    if temporal:
+        rel = max(oracle.check(spec, A, Ar)["max_rel"], oracle.check(spec, B, Br)["max_rel"])
+        h = spec.halo
+        ring = np.ones(A.shape, bool); ring[tuple(slice(h, s - h) for s in A.shape)] = False
+        return (rel <= (1e-6 if dtype == "fp32" else 1e-12) and np.array_equal(A[ring], Ar[ring]) and np.array_equal(B[ring], Br[ring])), True, rel
+    return bool(np.array_equal(A, Ar) and np.array_equal(B, Br)), False, 0.0
+
+
+def main():
+    n = int(sys.argv[1]) if len(sys.argv) > 1 else 120
+    jobs = make_jobs(n, int(sys.argv[2]) if len(sys.argv) > 2 else 1)
     t0 = time.time()
     with ProcessPoolExecutor(max_workers=16) as ex:
         errs = list(ex.map(build, jobs))
@@ -53,28 +79,15 @@ def main():
     bad = 0
     worst = {"fp32": 0.0, "fp64": 0.0}
     exact = 0
-    for (ndim, stc, dtype, args, step), k in kerns:
-        temporal = k.info.get("stages", 1) > 1
-        spec = oracle.Spec(stc, ndim, step)
-        A0 = oracle.fill_random(spec.shape, np.float32 if dtype == "fp32" else np.float64)
-        Ar, Br = A0.copy(), np.zeros_like(A0)
-        oracle.run(spec, Ar, Br, contract=1)
-        dA = torch.from_numpy(A0).cuda(); dB = torch.zeros_like(dA)
-        k.run(dA.data_ptr(), dB.data_ptr())
-        torch.cuda.synchronize()
-        A, B = dA.cpu().numpy(), dB.cpu().numpy()
+    for job, k in kerns:
+        good, temporal, rel = check(job, k, torch)
         if temporal:
-            rel = max(oracle.check(spec, A, Ar)["max_rel"], oracle.check(spec, B, Br)["max_rel"])
-            worst[dtype] = max(worst[dtype], rel)
-            h = spec.halo
-            ring = np.ones(A.shape, bool); ring[tuple(slice(h, s - h) for s in A.shape)] = False
-            good = rel <= (1e-6 if dtype == "fp32" else 1e-12) and np.array_equal(A[ring], Ar[ring]) and np.array_equal(B[ring], Br[ring])
+            worst[job[2]] = max(worst[job[2]], rel)
         else:
-            good = np.array_equal(A, Ar) and np.array_equal(B, Br)
             exact += good
         if not good:
             bad += 1
-            print("MISMATCH", " ".join(args[:-1]), os.path.basename(stc), flush=True)
+            print("MISMATCH", " ".join(job[3][:-1]), os.path.basename(job[1]), flush=True)
     print("%d configurations checked: %d single-pass bit-exact, %d temporal within tolerance (worst fp32 %.3g, fp64 %.3g), %d MISMATCHES"
           % (len(kerns), exact, len(kerns) - exact - bad, worst["fp32"], worst["fp64"], bad))
     sys.exit(1 if bad else 0)

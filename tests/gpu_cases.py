@@ -98,3 +98,11 @@ def golden_args(case, meta):
     opts = (["--3d"] if meta["ndim"] == 3 else []) + ["--dtype", "fp64", "--step", str(meta["step"]), "--dist", str(meta["macros"]["Dist"]),
                                                        "--bx", "16", "--by", "4", "--block-merge-x", "2", "--block-merge-y", my, "--sn", "4"]
     return opts, stc("gold_" + case)
+
+
+FUZZ_SAMPLE = (56, 5)   # (configurations, seed) of the sampled parity fuzz run by every GPU test session
+
+
+def fuzz_sample_jobs():
+    import fuzz_parity
+    return fuzz_parity.make_jobs(*FUZZ_SAMPLE)

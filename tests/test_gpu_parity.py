@@ -269,6 +269,28 @@ def test_reference_style_profile_flow():
     assert float(open(os.path.join(out, "duration.log")).read().split()[0]) == float(rec["Duration"])
 
 
+def test_sampled_parity_fuzz(torch_cuda):
+    """A fixed random sample of the tuner's space (all steps, fused and temporal, odd lane counts, both dtypes,
+    random prefetch depth) on the small ragged grids, against the oracle -- the configurations the hand-picked cases
+    above do not reach.  Kernels that spill to scratch are refused by the runtime and skipped (tests/fuzz_parity.py is
+    the full-size version of this sweep)."""
+    import drstencil_amd as drs
+    import fuzz_parity
+    from gpu_cases import fuzz_sample_jobs
+    checked = refused = 0
+    for job in fuzz_sample_jobs():
+        try:
+            k = drs.Kernel(job[3])           # cache hit: built at session start, before HIP was initialised
+        except drs.KernelBuildError as e:
+            assert "scratch" in str(e) or "Invalid configuration" in str(e) or "tile" in str(e), str(e)[-300:]
+            refused += 1
+            continue
+        good, temporal, rel = fuzz_parity.check(job, k, torch_cuda)
+        assert good, "%s (temporal=%s, rel=%g)" % (" ".join(job[3]), temporal, rel)
+        checked += 1
+    assert checked >= 30 and checked + refused == len(fuzz_sample_jobs())
+
+
 def test_native_library_is_the_path():
     import drstencil_amd as drs
     assert drs.lib() is not None
