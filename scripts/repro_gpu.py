@@ -1,5 +1,7 @@
 #!/usr/bin/env python3
-"""repro_gpu.py -- run a list of (stc, options) on the GPU against the oracle and describe any mismatch (debugging aid)."""
+"""repro_gpu.py -- the two kernels the round-1 parity fuzz found miscompiled (both spill to scratch; prefetch depth 2 was the
+automatic choice then), with option and -- via DRS_HIPCC=scripts/hipcc_wrappers/<x>.sh -- compiler-flag variants, against the oracle.
+Needs DRS_ALLOW_SCRATCH=1 (the runtime refuses such kernels now)."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -7,8 +9,8 @@ import numpy as np
 import drstencil_amd as drs
 
 BASE = {
-    "c": ("t3_cross", "--3d --dtype fp64 --bx 16 --by 8 --sn 4 --stream-unroll 4 --step 3 --dist 6 --block-merge-x 2 --block-merge-y 2 --merge-forward 5 --xrim dpp --xcd-remap 2"),
-    "o": ("t3_odd", "--3d --dtype fp64 --bx 32 --by 8 --sn 32 --stream-unroll 4 --step 3 --dist 3 --block-merge-x 2 --block-merge-y 2 --merge-forward 5 --xrim dpp --xcd-remap 2 --temporal 1"),
+    "c": ("t3_cross", "--3d --dtype fp64 --bx 16 --by 8 --sn 4 --stream-unroll 4 --step 3 --dist 6 --block-merge-x 2 --block-merge-y 2 --merge-forward 5 --prefetch --prefetch-depth 2 --xrim dpp --xcd-remap 2"),
+    "o": ("t3_odd", "--3d --dtype fp64 --bx 32 --by 8 --sn 32 --stream-unroll 4 --step 3 --dist 3 --block-merge-x 2 --block-merge-y 2 --merge-forward 5 --prefetch --prefetch-depth 2 --xrim dpp --xcd-remap 2 --temporal 1"),
 }
 VARIANTS = [""] if os.environ.get("ONLY_BASE") else ["", "--prefetch-depth 1", "--prefetch-depth 3", "--prefetch-auto 0", "--xrim lds", "--nt-store 0", "--clamp-loads 0", "--xcd-remap 0", "--schedule window"]
 
