@@ -25,6 +25,25 @@ def test_library_exports_every_declared_symbol():
     assert drs.lib().drs_version().startswith(b"drstencil-amd")
 
 
+def test_plain_c_host_links_and_uses_the_abi(tmp_path):
+    """tests/native/capi_host.c, compiled with gcc against include/drstencil_amd.h and the shared library: generator as
+    a function, error path, stencil IR getters, input fill -- the host-side surface, no GPU."""
+    import subprocess
+    exe = str(tmp_path / "capi_host")
+    subprocess.check_call(["gcc", "-std=c11", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "native", "capi_host.c"),
+                           "-o", exe, "-L", os.path.dirname(drs.LIB_PATH), "-ldrstencil_amd", "-Wl,-rpath," + os.path.dirname(drs.LIB_PATH)])
+    out = subprocess.run([exe, os.path.join(ROOT, "benchmarks", "3d7pt_star", "3d7pt_star.stc")], capture_output=True, text=True, timeout=60)
+    assert out.returncode == 0, out.stdout + out.stderr
+    lines = dict(ln.split(" ", 1) for ln in out.stdout.splitlines())
+    assert lines["version"].startswith("drstencil-amd")
+    assert lines["generate"].startswith("rc 0 ") and "has_kernel 1 has_gold 1" in lines["generate"]
+    assert lines["illegal"].startswith("rc 255 message Illegal input.")              # main.cpp:129-131
+    # 3d7pt_star fused twice: 25 points, Halo 2, Dist 2 (auto), Range 3, iterations 4 -> 2 launches (SURVEY.md section 2 table)
+    assert lines["spec"].startswith("status 0 dims 512 512 512 halo 2 dist 2 range 3 points 25 iterations 4 launches 2 ")
+    assert lines["point0"] == "-2 0 0 0.04"
+    assert lines["rand0"] == "0.84018773"                                            # first rand()/(RAND_MAX-1), common.hpp:9-45
+
+
 def test_missing_library_fails_loudly(monkeypatch, tmp_path):
     monkeypatch.setattr(drs, "_lib", None)
     monkeypatch.setattr(drs, "LIB_PATH", str(tmp_path / "nope.so"))
