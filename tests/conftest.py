@@ -128,6 +128,28 @@ def _run_reference_flow(drs):
         f.write("\n".join(log))
 
 
+def _run_c_host(drs):
+    """tests/native/capi_gpu_host.c (the INTEGRATION.md C example as a program) compiled with gcc and run as a child
+    process before this process touches HIP; the test reads its stdout."""
+    import subprocess
+    out = os.path.join(ROOT, "drstencil_amd", "_kcache", "c_host")
+    os.makedirs(out, exist_ok=True)
+    exe = os.path.join(out, "capi_gpu_host")
+    libdir = os.path.dirname(drs.LIB_PATH)
+    try:
+        cc = subprocess.run(["gcc", "-std=c11", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), "-I", "/opt/rocm/include",
+                             os.path.join(ROOT, "tests", "native", "capi_gpu_host.c"), "-o", exe, "-L", libdir, "-ldrstencil_amd", "-Wl,-rpath," + libdir,
+                             "-L/opt/rocm/lib", "-lamdhip64", "-Wl,-rpath,/opt/rocm/lib"], capture_output=True, text=True, timeout=120)
+        text = "[gcc rc=%d]\n%s" % (cc.returncode, cc.stderr[-1500:])
+        if cc.returncode == 0:
+            r = subprocess.run([exe, os.path.join(ROOT, "tests", "stc", "t3_star.stc"), "70", "45", "530", "2"], capture_output=True, text=True, timeout=300)
+            text += "[host rc=%d]\n%s%s" % (r.returncode, r.stdout, r.stderr[-800:])
+    except Exception as e:
+        text = "[exception] %r" % (e,)
+    with open(os.path.join(out, "stdout.txt"), "w") as f:
+        f.write(text)
+
+
 def pytest_sessionstart(session):
     """GPU sessions: make sure every kernel the gpu tests use is built (normally a cache hit:
     __graft_entry__.build() prebuilds them) BEFORE anything initialises HIP -- a process that
@@ -144,6 +166,7 @@ def pytest_sessionstart(session):
     _run_emitted_programs(drs)
     _run_tuner_smoke()
     _run_reference_flow(drs)
+    _run_c_host(drs)
     from gpu_cases import all_build_args, golden_args
     from helpers import golden_cases, load_golden
     jobs = all_build_args()

@@ -291,6 +291,20 @@ def test_sampled_parity_fuzz(torch_cuda):
     assert checked >= 30 and checked + refused == len(fuzz_sample_jobs())
 
 
+def test_c_host_through_the_abi():
+    """A plain-C host (tests/native/capi_gpu_host.c = the INTEGRATION.md example) built with gcc, run at session start:
+    drs_kernel_build, hipMalloc'ed buffers, drs_kernel_run_timed, the gold kernel through drs_kernel_run, drs_check_error --
+    no Python, no torch in that process."""
+    import re
+    text = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "drstencil_amd", "_kcache", "c_host", "stdout.txt")).read()
+    assert "[gcc rc=0]" in text and "[host rc=0]" in text, text[-1500:]
+    assert '"scratch_bytes_per_lane": 0' in text
+    m = re.search(r"launches (\d+) gold_launches (\d+) ms_positive (\d) rms (\S+) max_abs (\S+) max_rel (\S+)", text)
+    assert m, text[-800:]
+    assert m.group(1) == "2" and m.group(2) == "2" and m.group(3) == "1"          # Iterations 4, step 2 (codegen.hpp:581-584)
+    assert float(m.group(4)) == 0.0 and float(m.group(5)) == 1e-13 and float(m.group(6)) == 0.0    # bit-identical to the gold kernel
+
+
 def test_native_library_is_the_path():
     import drstencil_amd as drs
     assert drs.lib() is not None
