@@ -259,7 +259,7 @@ def main():
         for _ in range(args.warmup):
             run.run()
         torch.cuda.synchronize()
-        nwarm = max(0, int(MIN_WARM_S / 0.003) - args.warmup) if args.warmup > 0 else 0   # the same count on every rank (exchanges pair up)
+        nwarm = max(0, int(MIN_WARM_S / 0.003) * (1 if weak else pworld) - args.warmup) if args.warmup > 0 else 0   # ~MIN_WARM_S of runs; the same count on every rank (exchanges pair up)
         for _ in range(nwarm):
             run.run()
             warm_extra += 1
