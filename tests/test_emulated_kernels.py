@@ -2,6 +2,7 @@
 checks the generator's index math, guards, halo loaders, LDS exchange, register rotation,
 DPP path and prefetch pipeline without a GPU.  The GPU run of the same kernels is in
 test_gpu_parity.py."""
+import json
 import os
 
 import numpy as np
@@ -183,5 +184,50 @@ def test_emulated_asymmetric_stencils(vid, ndim, pts, dims, opts, tmp_path):
     assert run_emulated(lib, A, B, spec.iterations, step) == spec.launches
     if "--temporal" in opts:
         assert oracle.check(spec, A, A2)["max_rel"] < 1e-12 and oracle.check(spec, B, B2)["max_rel"] < 1e-12
+    else:
+        assert np.array_equal(A, A2) and np.array_equal(B, B2)
+
+
+def _emulated_fuzz_jobs(n=14, seed=9):
+    """A fixed random sample of the tuner's space on tiny ragged grids (the emulator runs one fiber per lane: grids stay
+    small and workgroups below 512 lanes)."""
+    import random
+    from drstencil_amd.tuner import tuning as t
+    mg = _mg()
+    rnd = random.Random(seed)
+    jobs = []
+    for ndim, pts, dims, order in [(3, "STAR3", (13, 21, 300), 1), (2, "STAR2", (1, 37, 300), 1), (2, "BOX25", (1, 29, 280), 2)]:
+        for dtype in ("fp32", "fp64"):
+            t.order, t.ndim, t.elem_bytes = order, ndim, 4 if dtype == "fp32" else 8
+            space = [v for v in t.enumerate_space((1, 2)) if v[2][0] * v[2][1] <= 256 and v[2][0] <= 66 and v[3] <= 16]
+            for v in rnd.sample(space, max(1, n // 6)):
+                cl = t.cfgToCommandLine(v).split()
+                if "--prefetch-depth" in cl:
+                    cl[cl.index("--prefetch-depth") + 1] = str(rnd.choice([1, 2, 3]))
+                jobs.append((t.cfgToString(v) + "_" + dtype + "_%dd" % ndim + pts.lower(), ndim, pts, dims, (["--3d"] if ndim == 3 else []) + ["--dtype", dtype] + cl, v[0]))
+    return jobs
+
+
+@pytest.mark.parametrize("vid,ndim,pts,dims,opts,step", _emulated_fuzz_jobs(), ids=[j[0] for j in _emulated_fuzz_jobs()])
+def test_emulated_sampled_fuzz(vid, ndim, pts, dims, opts, step, tmp_path):
+    """Random tuner-space configurations through the CPU emulator against the oracle: the emitter's logic without the
+    GPU compiler in the loop (the GPU-side sweeps are tests/fuzz_parity.py, tests/fuzz_gold.py)."""
+    mg = _mg()
+    stc = str(tmp_path / "f.stc")
+    write_stc(stc, ndim, dims, 4, getattr(mg, pts))
+    try:
+        lib = build_emulated(tmp_path, stc, opts)
+    except AssertionError as e:
+        assert "Invalid configuration" in str(e) or "tile" in str(e) or "halo" in str(e), str(e)[-300:]
+        pytest.skip("rejected by the generator")
+    spec = oracle.Spec(stc, ndim, step)
+    dt = np.float32 if "fp32" in opts else np.float64
+    A = oracle.fill_random(spec.shape, dt); B = np.zeros_like(A)
+    A2, B2 = A.copy(), B.copy()
+    oracle.run(spec, A2, B2, contract=1)
+    assert run_emulated(lib, A, B, spec.iterations, step) == spec.launches
+    if "--temporal" in opts and json.loads(lib.drs_plugin_info().decode()).get("stages", 1) > 1:
+        bar = 1e-6 if dt == np.float32 else 1e-12
+        assert oracle.check(spec, A, A2)["max_rel"] < bar and oracle.check(spec, B, B2)["max_rel"] < bar
     else:
         assert np.array_equal(A, A2) and np.array_equal(B, B2)
