@@ -200,7 +200,7 @@ def _emulated_fuzz_jobs(n=14, seed=9):
         for dtype in ("fp32", "fp64"):
             t.order, t.ndim, t.elem_bytes = order, ndim, 4 if dtype == "fp32" else 8
             space = [v for v in t.enumerate_space((1, 2)) if v[2][0] * v[2][1] <= 256 and v[2][0] <= 66 and v[3] <= 16]
-            for v in rnd.sample(space, max(1, n // 6)):
+            for v in rnd.sample(space, min(len(space), max(1, n // 6))):
                 cl = t.cfgToCommandLine(v).split()
                 if "--prefetch-depth" in cl:
                     cl[cl.index("--prefetch-depth") + 1] = str(rnd.choice([1, 2, 3]))
