@@ -117,9 +117,9 @@ def _run_reference_flow(drs):
                      "--block-merge-x", "4", "--block-merge-y", "2", "--merge-forward", "5", "--prefetch", "--xrim", "dpp", "--xcd-remap", "2",
                      "--check", "-o", "./cu/%s.hip" % name, "t3_star.stc"],
                     ["bash", os.path.join(tdir, "compile_run.sh"), name],
-                    [sys.executable, os.path.join(tdir, "getGpuMetrics.py"), name]):
+                    ["bash", os.path.join(tdir, "getGpuMetrics.sh")]):
             r = subprocess.run(cmd, cwd=out, env=env, capture_output=True, text=True, timeout=600)
-            log.append("[%s rc=%d]\n%s%s" % (os.path.basename(cmd[0] if cmd[0] != "bash" and cmd[0] != sys.executable else cmd[1]), r.returncode, r.stdout[-1500:], r.stderr[-1500:]))
+            log.append("[%s rc=%d]\n%s%s" % (os.path.basename(cmd[0] if cmd[0] != "bash" else cmd[1]), r.returncode, r.stdout[-1500:], r.stderr[-1500:]))
             if r.returncode != 0:
                 break
     except Exception as e:

@@ -250,13 +250,13 @@ def test_tuner_search_end_to_end():
 
 
 def test_reference_style_profile_flow():
-    """drstencil -> compile_run.sh (hipcc + the emitted program under rocprofv3, three runs) -> getGpuMetrics.py, run in
+    """drstencil -> compile_run.sh (hipcc + the emitted program under rocprofv3, three runs) -> getGpuMetrics.sh/.py, run in
     child processes at session start (tests/conftest.py): one gpuMetrics.csv row with the kernel's duration, the
     FETCH_SIZE / WRITE_SIZE traffic and the program's own check result, and a duration.log line."""
     import csv
     out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "drstencil_amd", "_kcache", "reference_flow")
     flow = open(os.path.join(out, "flow.txt")).read()
-    assert "[drstencil rc=0]" in flow and "[compile_run.sh rc=0]" in flow and "[getGpuMetrics.py rc=0]" in flow, flow[-2000:]
+    assert "[drstencil rc=0]" in flow and "[compile_run.sh rc=0]" in flow and "[getGpuMetrics.sh rc=0]" in flow, flow[-2000:]
     rows = list(csv.reader(open(os.path.join(out, "gpuMetrics.csv"))))
     assert rows[0][0] == "Metric Name" and len(rows) == 3
     rec = dict(zip(rows[0], rows[2]))
