@@ -190,11 +190,14 @@ def pytest_sessionstart(session):
     from drstencil_amd.multigpu import HipSweep, SlabPlan
     global SLAB_CACHE
     SLAB_CACHE = os.path.join(ROOT, "drstencil_amd", "_kcache")
-    for world, opts, halo in [(2, ["--3d", "--dtype", "fp32", "--sn", "8"], 1), (3, ["--3d", "--dtype", "fp32", "--step", "2", "--sn", "16"], 2),
-                              (2, ["--3d", "--dtype", "fp32", "--step", "2", "--temporal", "1", "--by", "8", "--block-merge-y", "4", "--sn", "16", "--prefetch"], 2)]:
-        sw = HipSweep(stcp("t3_star"), opts, SLAB_CACHE)
-        drs.Kernel(opts + [stcp("t3_star")])
+    from gpu_cases import SLAB_CASES
+    for cid, world, stencil, ndim, opts in SLAB_CASES:
+        step = int(opts[opts.index("--step") + 1]) if "--step" in opts else 1
+        spec = drs.Spec(stcp(stencil), ndim, step)
+        cut = spec.dims[0] if ndim == 3 else spec.dims[1]
+        sw = HipSweep(stcp(stencil), opts, SLAB_CACHE)
+        drs.Kernel(opts + [stcp(stencil)])
         for r in range(world):
             for every in (1, 2):
-                for lv in SlabPlan(70, halo, world, r, every).views():
+                for lv in SlabPlan(cut, spec.halo, world, r, every).views():
                     sw.kernel(lv)

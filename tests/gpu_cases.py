@@ -106,3 +106,13 @@ FUZZ_SAMPLE = (56, 5)   # (configurations, seed) of the sampled parity fuzz run 
 def fuzz_sample_jobs():
     import fuzz_parity
     return fuzz_parity.make_jobs(*FUZZ_SAMPLE)
+
+
+# slab decomposition on one GPU (tests/test_gpu_parity.py::test_slab_decomposition_on_one_gpu): (id, world, stencil, ndim, options)
+SLAB_CASES = [
+    ("w2_step1", 2, "t3_star", 3, ["--3d", "--dtype", "fp32", "--sn", "8"]),
+    ("w3_fused2", 3, "t3_star", 3, ["--3d", "--dtype", "fp32", "--step", "2", "--sn", "16"]),
+    ("w2_temporal2", 2, "t3_star", 3, ["--3d", "--dtype", "fp32", "--step", "2", "--temporal", "1", "--by", "8", "--block-merge-y", "4", "--sn", "16", "--prefetch"]),
+    ("w2_2d_box25_tile", 2, "t2_box25", 2, ["--dtype", "fp64"]),
+    ("w3_2d_star_stream_step2", 3, "t2_star", 2, ["--dtype", "fp32", "--streaming", "--step", "2", "--sn", "16"]),
+]

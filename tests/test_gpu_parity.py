@@ -358,31 +358,32 @@ class _FakeDist:
         return [self._Work() for _ in ops]
 
 
+from gpu_cases import SLAB_CASES
+
+
 @pytest.mark.parametrize("every", [1, 2], ids=["exchange_every_launch", "exchange_every_pair"])
-@pytest.mark.parametrize("world,opts", [
-    (2, ["--3d", "--dtype", "fp32", "--sn", "8"]),
-    (3, ["--3d", "--dtype", "fp32", "--step", "2", "--sn", "16"]),
-    (2, ["--3d", "--dtype", "fp32", "--step", "2", "--temporal", "1", "--by", "8", "--block-merge-y", "4", "--sn", "16", "--prefetch"]),
-], ids=["w2_step1", "w3_fused2", "w2_temporal2"])
-def test_slab_decomposition_on_one_gpu(torch_cuda, world, opts, every, tmp_path):
-    """z-slab decomposition (drstencil_amd.multigpu) with every rank on this GPU == the
+@pytest.mark.parametrize("cid,world,stencil,ndim,opts", SLAB_CASES, ids=[c[0] for c in SLAB_CASES])
+def test_slab_decomposition_on_one_gpu(torch_cuda, cid, world, stencil, ndim, opts, every, tmp_path):
+    """Slab decomposition (drstencil_amd.multigpu: z slabs in 3D, y slabs in 2D) with every rank on this GPU == the
     single-domain run of the same kernel, bit for bit."""
     import drstencil_amd as drs
     from drstencil_amd.multigpu import HipSweep, SlabRun
     from gpu_cases import stc as stcp
     torch = torch_cuda
-    stc = stcp("t3_star")    # 70 x 45 x 530
+    stc = stcp(stencil)
     step = _step(opts)
     full = drs.Kernel(opts + [stc])
-    spec = oracle.Spec(stc, 3, step)
+    spec = oracle.Spec(stc, ndim, step)
     L, M, N = spec.dims
     H = spec.halo
-    A0 = oracle.fill_random(spec.shape, np.float32)
+    dt = _dtype(opts)
+    tdt = torch.float32 if dt == np.float32 else torch.float64
+    A0 = oracle.fill_random(spec.shape, dt)
     n_ref, A_ref, B_ref = run_hip(torch, full, A0, np.zeros_like(A0))
     hub = _Hub()
     dev = torch.device("cuda", 0)
     sweep = HipSweep(stc, opts, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "drstencil_amd", "_kcache"))
-    runs = [SlabRun(torch, _FakeDist(hub, r), (L, M, N), H, step, spec.iterations, r, world, sweep, dev, torch.float32, every=every) for r in range(world)]
+    runs = [SlabRun(torch, _FakeDist(hub, r), (L, M, N) if ndim == 3 else (M, N), H, step, spec.iterations, r, world, sweep, dev, tdt, every=every) for r in range(world)]
     for r in runs:
         r.load_global(lambda lo, hi: A0[lo:hi])
     t, n = 0, 0
