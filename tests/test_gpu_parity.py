@@ -376,7 +376,7 @@ def test_slab_decomposition_on_one_gpu(torch_cuda, cid, world, stencil, ndim, op
     spec = oracle.Spec(stc, ndim, step)
     L, M, N = spec.dims
     H = spec.halo
-    dt = _dtype(opts)
+    dt = _np_dtype(_dtype(opts))
     tdt = torch.float32 if dt == np.float32 else torch.float64
     A0 = oracle.fill_random(spec.shape, dt)
     n_ref, A_ref, B_ref = run_hip(torch, full, A0, np.zeros_like(A0))
