@@ -18,6 +18,12 @@ STAR2 = [(0, 0, 0.3), (0, 1, 0.2), (1, 0, 0.15), (0, -1, 0.25), (-1, 0, 0.1)]
 BOX25 = [(j, i, 0.04 + 0.001 * (5 * j + i)) for j in range(-2, 3) for i in range(-2, 3)]
 SPECS = [(3, "g3_star", (90, 150, 2100), STAR3, 1, False), (3, "g3_cross", (70, 130, 1540), CROSS3, 1, True),
          (2, "g2_star", (1, 3000, 5000), STAR2, 1, False), (2, "g2_box25", (1, 2100, 4100), BOX25, 2, False)]
+if os.environ.get("FUZZ_GOLD_BIG"):   # BASELINE sizes: offsets beyond 2^31 bytes, thousands of tiles (fp32 3D / fp64 2D only, to bound the run)
+    SPECS = [(3, "b3_star_1024", (1024, 1024, 1024), STAR3, 1, False), (2, "b2_box25_16384", (1, 16384, 16384), BOX25, 2, False),
+             (2, "b2_star_8192", (1, 8192, 8192), STAR2, 1, False)]
+    DTYPES = {"b3_star_1024": ("fp32",), "b2_box25_16384": ("fp64",), "b2_star_8192": ("fp32",)}
+else:
+    DTYPES = {}
 
 
 def build(job):
@@ -35,10 +41,10 @@ def main():
     for ndim, name, dims, pts, order, cross in SPECS:
         stc = os.path.join(out, name + ".stc")
         write_stc(stc, ndim, dims, 4, pts)
-        for dtype in ("fp32", "fp64"):
+        for dtype in DTYPES.get(name, ("fp32", "fp64")):
             t.order, t.ndim, t.elem_bytes = order, ndim, 4 if dtype == "fp32" else 8
             space = t.enumerate_space((1, 2, 3) if order == 1 and not cross else (1, 2))
-            for v in random.sample(space, min(len(space), max(1, n // (2 * len(SPECS))))):
+            for v in random.sample(space, min(len(space), max(1, n // (len(DTYPES.get(name, (1, 2))) * len(SPECS))))):
                 cl = t.cfgToCommandLine(v).split()
                 if cross:
                     i = cl.index("--dist"); cl[i + 1] = str(2 * v[0])
