@@ -241,6 +241,7 @@ def main():
         ev_ms = e0.elapsed_time(e1)
         assert n == launches_per_step * args.steps
         kinfo = kern.info
+        kres = kern.resources
         parallelism = "1 GPU"
         def side(k, o, iters):
             # side measurement on the same grid (reference protocol: warm-up launches, then the timed
@@ -282,6 +283,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         el, ev_ms = float(t[0]), float(t[1])
         kinfo = sweep.kernel(run.plan.interior[1] - run.plan.interior[0]).info
+        kres = sweep.kernel(run.plan.interior[1] - run.plan.interior[0]).resources
         parallelism = "%s-slab x%d%s, RCCL send/recv halo every %d launch(es), overlapped" % ("z" if w["ndim"] == 3 else "y", pworld, " (weak: grid %s)" % "x".join(str(d) for d in ((L, M, N) if w["ndim"] == 3 else (M, N))) if weak else "", args.exchange_every)
         step1 = fused2 = None
 
@@ -304,7 +306,9 @@ def main():
             "vs_baseline": None, "dtype": "f32" if w["dtype"] == "fp32" else "f64", "data": "synthetic",
             "config": {"workload": w["name"], "generator_options": " ".join(opts), "step": step,
                        "launches_per_step": launches_per_step, "parallelism": parallelism,
-                       "kernel": "dr_" + kinfo["name"], "threads": kinfo["threads"], "lds_bytes": kinfo["lds_bytes"]},
+                       "kernel": "dr_" + kinfo["name"], "threads": kinfo["threads"], "lds_bytes": kinfo["lds_bytes"],
+                       "vgprs": kres.get("vgprs"), "agprs": kres.get("agprs"), "scratch_bytes_per_lane": kres.get("scratch_bytes_per_lane"),
+                       "occupancy_waves_per_simd": kres.get("occupancy_waves_per_simd")},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(args.workload, " ".join(opts)) if pworld == 1 else None,
                          "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": avg_launch_s * 1e3},
