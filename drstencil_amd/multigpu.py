@@ -103,6 +103,55 @@ def choose_exchange_every(planes_per_rank, plane_bytes, H, link_GBps=60.0, kerne
     return 2 if planes_per_rank >= 8 * H and sweep_us >= 1.3 * xfer_us else 1
 
 
+def measure_exchange_every(torch, dist, dims, H, rank, world, sweep, device, dtype, reps=6, self_neighbour=False):
+    """The same decision as choose_exchange_every, from numbers measured on the machine the run is on (called during
+    warm-up, before the slab buffers exist): one interior sweep of this rank's slab against one exchange of 2H planes per
+    face with the real neighbours through the real process group; MAX over ranks, so every rank decides alike.
+    Returns (every, sweep_us, exchange_us)."""
+    dims = tuple(dims)
+    p = SlabPlan(dims[0], H, world, rank, 1)
+    rest = dims[1:]
+    main = torch.cuda.current_stream(device)
+    src = torch.zeros((p.Lloc,) + rest, dtype=dtype, device=device)
+    dst = torch.zeros_like(src)
+    a, b = p.interior
+
+    def timed(fn):
+        for _ in range(2):
+            fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(main)
+        for _ in range(reps):
+            fn()
+        e1.record(main)
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / reps * 1e3
+
+    sweep_us = timed(lambda: sweep(src[a:b], dst[a:b], main.cuda_stream))
+    G = 2 * H
+    up = 0 if self_neighbour else rank - 1
+    dn = 0 if self_neighbour else rank + 1
+    has_up, has_dn = (p.has_up or self_neighbour), (p.has_dn or self_neighbour)
+    bufs = [torch.zeros((G,) + rest, dtype=dtype, device=device) for _ in range(4)]
+
+    def exchange():
+        ops = []
+        if has_up:
+            ops += [dist.P2POp(dist.isend, bufs[0], up), dist.P2POp(dist.irecv, bufs[1], dn if self_neighbour else up)]
+        if has_dn:
+            ops += [dist.P2POp(dist.isend, bufs[2], dn), dist.P2POp(dist.irecv, bufs[3], up if self_neighbour else dn)]
+        for w in dist.batch_isend_irecv(ops):
+            w.wait()
+
+    xfer_us = timed(exchange) if (has_up or has_dn) else 0.0
+    t = torch.tensor([sweep_us, xfer_us], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    sweep_us, xfer_us = float(t[0]), float(t[1])
+    thick = min(slab_bounds(dims[0], world, r)[1] - slab_bounds(dims[0], world, r)[0] for r in range(world)) >= 8 * H
+    return (2 if thick and sweep_us >= 1.3 * xfer_us else 1), sweep_us, xfer_us
+
+
 def _write_view_stc(base_stc, ndim, L_view, cache_dir, tag):
     """A copy of the spec with its outermost size (L in 3D, M in 2D) replaced (reference .stc format)."""
     import re
