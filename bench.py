@@ -255,9 +255,8 @@ def main():
         fused2 = side(kernf, TEMPORAL2[args.workload], 32) if kernf is not None else None
     else:
         if auto_every:
-            args.exchange_every, sw_us, xf_us = measure_exchange_every(torch, dist, (L, M, N) if w["ndim"] == 3 else (M, N), H, prank, pworld, sweep, dev, tdt,
+            args.exchange_every, calibration = measure_exchange_every(torch, dist, (L, M, N) if w["ndim"] == 3 else (M, N), H, prank, pworld, sweep, dev, tdt,
                                                                        self_neighbour=bool(rehearse))
-            calibration = {"interior_sweep_us": sw_us, "exchange_2H_planes_us": xf_us, "chosen_every": args.exchange_every}
         run = (SelfNeighbourRun if rehearse else SlabRun)(torch, dist, (L, M, N) if w["ndim"] == 3 else (M, N), H, step, iters, prank, pworld, sweep, dev, tdt, every=args.exchange_every)
         g = torch.Generator(device=dev).manual_seed(1 + prank)
         run.A.copy_(torch.rand(run.A.shape, dtype=tdt, device=dev, generator=g))

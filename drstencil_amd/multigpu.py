@@ -106,8 +106,8 @@ def choose_exchange_every(planes_per_rank, plane_bytes, H, link_GBps=60.0, kerne
 def measure_exchange_every(torch, dist, dims, H, rank, world, sweep, device, dtype, reps=6, self_neighbour=False):
     """The same decision as choose_exchange_every, from numbers measured on the machine the run is on (called during
     warm-up, before the slab buffers exist): one interior sweep of this rank's slab against one exchange of 2H planes per
-    face with the real neighbours through the real process group; MAX over ranks, so every rank decides alike.
-    Returns (every, sweep_us, exchange_us)."""
+    face (and of H planes) with the real neighbours through the real process group; MAX over ranks, so every rank
+    decides alike: the mode with the shorter estimated ping-pong pair wins.  Returns (every, measurements)."""
     dims = tuple(dims)
     p = SlabPlan(dims[0], H, world, rank, 1)
     rest = dims[1:]
@@ -129,27 +129,35 @@ def measure_exchange_every(torch, dist, dims, H, rank, world, sweep, device, dty
         return e0.elapsed_time(e1) / reps * 1e3
 
     sweep_us = timed(lambda: sweep(src[a:b], dst[a:b], main.cuda_stream))
-    G = 2 * H
     up = 0 if self_neighbour else rank - 1
     dn = 0 if self_neighbour else rank + 1
     has_up, has_dn = (p.has_up or self_neighbour), (p.has_dn or self_neighbour)
-    bufs = [torch.zeros((G,) + rest, dtype=dtype, device=device) for _ in range(4)]
 
-    def exchange():
-        ops = []
-        if has_up:
-            ops += [dist.P2POp(dist.isend, bufs[0], up), dist.P2POp(dist.irecv, bufs[1], dn if self_neighbour else up)]
-        if has_dn:
-            ops += [dist.P2POp(dist.isend, bufs[2], dn), dist.P2POp(dist.irecv, bufs[3], up if self_neighbour else dn)]
-        for w in dist.batch_isend_irecv(ops):
-            w.wait()
+    def exchange_us(G):
+        bufs = [torch.zeros((G,) + rest, dtype=dtype, device=device) for _ in range(4)]
 
-    xfer_us = timed(exchange) if (has_up or has_dn) else 0.0
-    t = torch.tensor([sweep_us, xfer_us], dtype=torch.float64, device=device)
+        def exchange():
+            ops = []
+            if has_up:
+                ops += [dist.P2POp(dist.isend, bufs[0], up), dist.P2POp(dist.irecv, bufs[1], dn if self_neighbour else up)]
+            if has_dn:
+                ops += [dist.P2POp(dist.isend, bufs[2], dn), dist.P2POp(dist.irecv, bufs[3], up if self_neighbour else dn)]
+            for w in dist.batch_isend_irecv(ops):
+                w.wait()
+        return timed(exchange) if (has_up or has_dn) else 0.0
+
+    x1, x2 = exchange_us(H), exchange_us(2 * H)
+    t = torch.tensor([sweep_us, x1, x2], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    sweep_us, xfer_us = float(t[0]), float(t[1])
-    thick = min(slab_bounds(dims[0], world, r)[1] - slab_bounds(dims[0], world, r)[0] for r in range(world)) >= 8 * H
-    return (2 if thick and sweep_us >= 1.3 * xfer_us else 1), sweep_us, xfer_us
+    sweep_us, x1, x2 = float(t[0]), float(t[1]), float(t[2])
+    planes = min(slab_bounds(dims[0], world, r)[1] - slab_bounds(dims[0], world, r)[0] for r in range(world))
+    # time of one ping-pong pair (two launches) in each mode; ~30 us per exchanging launch for the two boundary kernels
+    # and the stream hand-overs around them (profiles/r01_rccl_probe.md)
+    pair1 = 2.0 * (30.0 + max(sweep_us, x1))
+    pair2 = sweep_us * (1.0 + 2.0 * H / planes) + 30.0 + max(sweep_us, x2)
+    every = 2 if planes >= 8 * H and pair2 < pair1 else 1
+    return every, {"interior_sweep_us": sweep_us, "exchange_H_planes_us": x1, "exchange_2H_planes_us": x2,
+                   "pair_us_exchange_every_launch": pair1, "pair_us_one_exchange_per_pair": pair2, "chosen_every": every}
 
 
 def _write_view_stc(base_stc, ndim, L_view, cache_dir, tag):
