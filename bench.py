@@ -188,8 +188,7 @@ def main():
         auto_every = args.exchange_every == 0      # decided after the process group is up, from measured sweep / exchange times
         sweep = HipSweep(w["stc"], opts, os.path.join(ROOT, "drstencil_amd", "_kcache"))
         for ev in ((1, 2) if auto_every else (args.exchange_every,)):      # both modes' kernels: built (cache hits) before HIP is up
-            for lv in SlabPlan(L if w["ndim"] == 3 else M, H, pworld, prank, ev).views():
-                sweep.kernel(lv)
+            sweep.prebuild(SlabPlan(L if w["ndim"] == 3 else M, H, pworld, prank, ev))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the product path has no CPU fallback)")
     torch.cuda.set_device(local_rank)

@@ -57,6 +57,7 @@ def lib():
     L.drs_kernel_resources.argtypes = [vp]
     L.drs_kernel_launch.argtypes = [vp, vp, vp, vp]
     L.drs_kernel_launch_gold.argtypes = [vp, vp, vp, vp]
+    L.drs_kernel_launch_pair.argtypes = [vp, vp, vp, vp, vp, vp]
     L.drs_kernel_run.argtypes = [vp, vp, vp, ci, ci, vp]
     L.drs_kernel_run_timed.argtypes = [vp, vp, vp, ci, ci, vp, ctypes.POINTER(ctypes.c_float)]
     L.drs_fill_random_f64.argtypes = [vp, ctypes.c_size_t, ctypes.c_uint]
@@ -73,7 +74,7 @@ EXPORTS = [
     "drs_version", "drs_free", "drs_generate",
     "drs_spec_open", "drs_spec_close", "drs_spec_halo", "drs_spec_dist", "drs_spec_range", "drs_spec_npoints",
     "drs_spec_iterations", "drs_spec_launches", "drs_spec_dims", "drs_spec_point", "drs_spec_partition",
-    "drs_kernel_build", "drs_kernel_close", "drs_kernel_info", "drs_kernel_path", "drs_kernel_resources", "drs_kernel_launch",
+    "drs_kernel_build", "drs_kernel_close", "drs_kernel_info", "drs_kernel_path", "drs_kernel_resources", "drs_kernel_launch", "drs_kernel_launch_pair",
     "drs_kernel_launch_gold", "drs_kernel_run", "drs_kernel_run_timed",
     "drs_fill_random_f64", "drs_fill_random_f32", "drs_check_error_f64", "drs_check_error_f32",
 ]
@@ -181,6 +182,12 @@ class Kernel:
         rc = lib().drs_kernel_launch(self.h, d_in, d_out, stream)
         if rc != 0:
             raise RuntimeError("HIP launch error %d" % rc)
+
+    def launch_pair(self, d_in0, d_out0, d_in1, d_out1, stream=0):
+        """One launch over two (in, out) pairs (kernels generated with --pair-launch 1)."""
+        rc = lib().drs_kernel_launch_pair(self.h, d_in0, d_out0, d_in1, d_out1, stream)
+        if rc != 0:
+            raise RuntimeError("pair launch error %d (-2: kernel built without --pair-launch 1)" % rc)
 
     def launch_gold(self, d_in, d_out, stream=0):
         rc = lib().drs_kernel_launch_gold(self.h, d_in, d_out, stream)

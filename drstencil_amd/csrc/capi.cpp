@@ -29,6 +29,7 @@ struct drs_kernel {
     void *dl = nullptr;
     int (*launch)(const void *, void *, hipStream_t) = nullptr;
     int (*launch_gold)(const void *, void *, hipStream_t) = nullptr;
+    int (*launch_pair)(const void *, void *, const void *, void *, hipStream_t) = nullptr;   // only with --pair-launch 1
     const char *(*info)(void) = nullptr;
     std::string path;
     std::string resources;   // JSON: register / scratch / LDS use of dr_<name> as reported by the compiler
@@ -260,6 +261,7 @@ drs_kernel *drs_kernel_build(int argc, const char *const *argv, const char *cach
     k->dl = dl;
     k->launch = (int (*)(const void *, void *, hipStream_t))dlsym(dl, "drs_plugin_launch");
     k->launch_gold = (int (*)(const void *, void *, hipStream_t))dlsym(dl, "drs_plugin_launch_gold");
+    k->launch_pair = (int (*)(const void *, void *, const void *, void *, hipStream_t))dlsym(dl, "drs_plugin_launch_pair");
     k->info = (const char *(*)(void))dlsym(dl, "drs_plugin_info");
     k->path = so;
     k->resources = resources;
@@ -284,6 +286,10 @@ const char *drs_kernel_resources(const drs_kernel *k) { return k->resources.c_st
 
 int drs_kernel_launch(drs_kernel *k, const void *d_in, void *d_out, void *stream) {
     return k->launch(d_in, d_out, (hipStream_t)stream);
+}
+int drs_kernel_launch_pair(drs_kernel *k, const void *d_in0, void *d_out0, const void *d_in1, void *d_out1, void *stream) {
+    if (!k->launch_pair) return -2;      // the kernel was not generated with --pair-launch 1
+    return k->launch_pair(d_in0, d_out0, d_in1, d_out1, (hipStream_t)stream);
 }
 int drs_kernel_launch_gold(drs_kernel *k, const void *d_in, void *d_out, void *stream) {
     return k->launch_gold(d_in, d_out, (hipStream_t)stream);

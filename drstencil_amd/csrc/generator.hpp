@@ -81,6 +81,7 @@ MI355X options:
                         intermediate planes never leave the CU) instead of the fused stencil.
 --prefetch-depth <n>    With --prefetch: planes in flight ahead of the one being summed (n+1 register sets; default 3 (fp32) /
                         2 (fp64) for fused multi-step 3D kernels, else 1).
+--pair-launch <0|1>     Also emit dr2_<name>(in0, out0, in1, out1): the same sweep over two buffer pairs in one launch.
 --exact-y <0|1>         1 (default for single-stage kernels): the y halo rows of the source plane are fetched by the halo loader
                         lanes, so every tile row is owned; 0: overlapped tiles (tile rows include the halo).
 --clamp-loads <0|1>     1 (default): branch-free loads -- lanes outside the grid read the plane origin (their
@@ -148,6 +149,7 @@ inline GenResult generate(const std::vector<std::string> &args /* argv[1..] */) 
         else if (a == "--clamp-loads") { if (!int_opt(o.clamp_loads, nullptr)) break; }
         else if (a == "--halo-spread") { if (!int_opt(o.halo_spread, nullptr)) break; }
         else if (a == "--zgroup") { if (!int_opt(o.zgroup, nullptr)) break; }
+        else if (a == "--pair-launch") { if (!int_opt(o.pair_launch, nullptr)) break; }
         else if (a == "--prefetch-auto") { if (!int_opt(o.prefetch_auto, nullptr)) break; }
         else if (a == "--prefetch-depth") { if (!int_opt(o.prefetch_depth, nullptr)) break; }
         else if (a == "--temporal") { if (!int_opt(o.temporal, nullptr)) break; }

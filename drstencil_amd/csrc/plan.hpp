@@ -64,6 +64,8 @@ struct GenOptions {
     int clamp_loads = 1;         // branch-free loads (out-of-grid lanes read the plane origin) and uniform-guarded scalar stores
     int halo_spread = 0;         // spread the halo loader tasks over all wavefronts of the workgroup (no gain measured)
     int xedge_select = 0;        // --xrim dpp: wavefront-edge lanes take the LDS value by select instead of a branch
+    int pair_launch = 0;         // also emit dr2_<name>(in0, out0, in1, out1): one launch over two (in, out) pairs, chosen by blockIdx.y
+                                 // (the two boundary views of a slab-decomposed run)
     int zgroup = 4;              // --xcd-remap 3: stream blocks of one tile taken by consecutive workgroups
     int prefetch_auto = 1;       // 3D kernels with step > 1 (fused or temporal) prefetch unless --prefetch-auto 0 (+28 % measured)
     int prefetch_depth = -1;     // planes in flight ahead of the one being summed (register sets = depth + 1); -1 auto:

@@ -76,6 +76,12 @@ class SlabPlan:
         self.send_dn = (self.Lloc - 2 * G, self.Lloc - G) if self.has_dn else None
         self.recv_dn = (self.Lloc - G, self.Lloc) if self.has_dn else None
 
+    def pair_view(self):
+        """Length of the two boundary views when the rank has both (they go out in ONE launch of a --pair-launch kernel)."""
+        if self.top is not None and self.bot is not None and self.top[1] - self.top[0] == self.bot[1] - self.bot[0]:
+            return self.top[1] - self.top[0]
+        return None
+
     def views(self):
         """Every view length this rank launches a kernel on (for prebuilding)."""
         out = [v[1] - v[0] for v in (self.top, self.bot, self.interior) if v is not None and v[1] - v[0] > 2 * self.H]
@@ -193,11 +199,22 @@ class HipSweep:
         os.makedirs(cache_dir, exist_ok=True)
         self.kernels = {}
 
-    def kernel(self, Lv):
-        if Lv not in self.kernels:
+    def kernel(self, Lv, pair=False):
+        if (Lv, pair) not in self.kernels:
             stc = _write_view_stc(self.base_stc, self.ndim, Lv, self.cache_dir, "slabL")
-            self.kernels[Lv] = drs.Kernel(self.opts + [stc])
-        return self.kernels[Lv]
+            self.kernels[(Lv, pair)] = drs.Kernel(self.opts + (["--pair-launch", "1"] if pair else []) + [stc])
+        return self.kernels[(Lv, pair)]
+
+    def prebuild(self, plan):
+        """Build (or find cached) every kernel `plan` launches -- call before HIP is initialised."""
+        for lv in plan.views():
+            self.kernel(lv)
+        if plan.pair_view():
+            self.kernel(plan.pair_view(), pair=True)
+
+    def pair(self, src0, dst0, src1, dst1, stream):
+        """Both boundary views in one launch."""
+        self.kernel(src0.shape[0], pair=True).launch_pair(src0.data_ptr(), dst0.data_ptr(), src1.data_ptr(), dst1.data_ptr(), stream)
 
     def __call__(self, src_view, dst_view, stream):
         k = self.kernel(src_view.shape[0])
@@ -260,9 +277,12 @@ class SlabRun:
         a, b = p.interior
         if self.gpu and self.world > 1:
             sh = self.main.cuda_stream
-            for v in (p.top, p.bot):
-                if v is not None:
-                    self.sweep(src[v[0]:v[1]], dst[v[0]:v[1]], sh)
+            if p.pair_view() and hasattr(self.sweep, "pair"):
+                self.sweep.pair(src[p.top[0]:p.top[1]], dst[p.top[0]:p.top[1]], src[p.bot[0]:p.bot[1]], dst[p.bot[0]:p.bot[1]], sh)
+            else:
+                for v in (p.top, p.bot):
+                    if v is not None:
+                        self.sweep(src[v[0]:v[1]], dst[v[0]:v[1]], sh)
             self.ev_b.record(self.main)
             if b - a > 2 * H:
                 self.sweep(src[a:b], dst[a:b], sh)

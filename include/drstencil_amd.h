@@ -59,6 +59,9 @@ const char *drs_kernel_path(const drs_kernel *k);   /* the loaded shared object 
 const char *drs_kernel_resources(const drs_kernel *k);
 /* one launch of dr_<name><<<grid, block, 0, stream>>>(in, out): codegen.hpp:577,582-583 */
 int drs_kernel_launch(drs_kernel *k, const void *d_in, void *d_out, void *stream);
+/* one launch of dr2_<name>: the same sweep over TWO (in, out) pairs (kernels generated with --pair-launch 1; -2 otherwise).
+ * No reference counterpart: the two boundary views of a slab-decomposed run (drstencil_amd/multigpu.py) in one launch. */
+int drs_kernel_launch_pair(drs_kernel *k, const void *d_in0, void *d_out0, const void *d_in1, void *d_out1, void *stream);
 /* one launch of gold_<name> (the reference's verification kernel, codegen.hpp:611-612) */
 int drs_kernel_launch_gold(drs_kernel *k, const void *d_in, void *d_out, void *stream);
 /* the timed ping-pong loop: for (t = 0; t < iterations; t += 2*step) { k(A,B); k(B,A); }

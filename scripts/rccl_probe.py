@@ -39,8 +39,7 @@ def main():
     H, step, iters = spec.halo, spec.step, spec.iterations
     sweep = HipSweep(w["stc"], opts, os.path.join(ROOT, "drstencil_amd", "_kcache"))
     frank = a.world // 2 - 1
-    for lv in SlabPlan(L, H, a.world, frank, a.every).views():
-        sweep.kernel(lv)
+    sweep.prebuild(SlabPlan(L, H, a.world, frank, a.every))
 
     import torch
     import torch.distributed as dist

@@ -199,5 +199,4 @@ def pytest_sessionstart(session):
         drs.Kernel(opts + [stcp(stencil)])
         for r in range(world):
             for every in (1, 2):
-                for lv in SlabPlan(cut, spec.halo, world, r, every).views():
-                    sw.kernel(lv)
+                sw.prebuild(SlabPlan(cut, spec.halo, world, r, every))

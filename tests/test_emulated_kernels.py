@@ -231,3 +231,20 @@ def test_emulated_sampled_fuzz(vid, ndim, pts, dims, opts, step, tmp_path):
         assert oracle.check(spec, A, A2)["max_rel"] < bar and oracle.check(spec, B, B2)["max_rel"] < bar
     else:
         assert np.array_equal(A, A2) and np.array_equal(B, B2)
+
+
+def test_emulated_pair_launch(tmp_path):
+    """--pair-launch 1: dr2_<name> over two (in, out) pairs in one launch == two launches of dr_<name>."""
+    import ctypes
+    mg = _mg()
+    stc = str(tmp_path / "p.stc")
+    write_stc(stc, 3, (9, 21, 140), 4, mg.STAR3)
+    lib = build_emulated(tmp_path, stc, ["--3d", "--dtype", "fp32", "--step", "2", "--sn", "4", "--pair-launch", "1", "--bx", "16", "--by", "4", "--block-merge-y", "2"])
+    lib.drs_plugin_launch_pair.argtypes = [ctypes.c_void_p] * 5
+    spec = oracle.Spec(stc, 3, 2)
+    a0 = oracle.fill_random(spec.shape, np.float32)
+    a1 = (a0[::-1] * np.float32(0.5)).copy()
+    o0, o1, r0, r1 = (np.zeros_like(a0) for _ in range(4))
+    assert lib.drs_plugin_launch_pair(a0.ctypes.data, o0.ctypes.data, a1.ctypes.data, o1.ctypes.data, None) == 0
+    assert lib.drs_plugin_launch(a0.ctypes.data, r0.ctypes.data, None) == 0 and lib.drs_plugin_launch(a1.ctypes.data, r1.ctypes.data, None) == 0
+    assert np.array_equal(o0, r0) and np.array_equal(o1, r1) and o0.any() and not np.array_equal(o0, o1)
