@@ -9,7 +9,8 @@ the global frozen ring stays on the outer faces of rank 0 and rank R-1, every la
 <= 2 neighbours, and both ping-pong buffers carry H ghost planes per interior face.
 
 Per launch and rank (boundary first, so the exchange overlaps the interior sweep):
-    main stream : boundary kernels (first/last H owned planes) -> event b ; interior kernel ; wait c
+    main stream : boundary views (first/last owned planes; ONE launch of a --pair-launch kernel when the rank has two
+                  neighbours) -> event b ; interior kernel ; wait c
     side stream : wait b; batch_isend_irecv of dst's boundary planes -> event c
 Three things measured with scripts/rccl_probe.py (profiles/r01_rccl_probe.md) shape this:
   * the interior kernel is enqueued BEFORE the RCCL call is made -- batch_isend_irecv costs ~100 us of host time
@@ -18,7 +19,7 @@ Three things measured with scripts/rccl_probe.py (profiles/r01_rccl_probe.md) sh
     ProcessGroupNCCL.Options(is_high_priority_stream=True), see nccl_options()): HIP multiplexes streams of one
     priority onto a few in-order hardware queues, and an RCCL kernel that lands on the interior kernel's queue
     runs only after it;
-  * the boundary kernels stay in front of the interior kernel on the same stream (2 x 10 us): beside it they wait
+  * the boundary views stay in front of the interior kernel on the same stream (~10 us): beside it they wait
     55 us each for the long-lived stream blocks of the interior kernel to release their CUs.
 Critical path per launch = boundary + max(interior, exchange).  Each neighbour pair talks over its own xGMI link;
 nothing is all-reduced in the loop.
@@ -28,7 +29,7 @@ is followed by an exchange; the launch before it sweeps the whole local slab on 
 
 Kernels are ordinary generated kernels: a z sub-range of a slab is a contiguous view, so
 a "boundary kernel" is the generator's kernel for L = G + 2H planes (G = ghost width) and the interior kernel
-the one for the remaining view -- no special device code.
+the one for the remaining view -- no special device code (dr2_<name> is the same body over two buffer pairs).
 """
 import os
 
