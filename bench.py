@@ -61,23 +61,15 @@ TEMPORAL2 = {
     "c4": ["--3d", "--dtype", "fp32", "--step", "2", "--temporal", "1", "--prefetch", "--bx", "66", "--by", "15", "--block-merge-x", "4", "--block-merge-y", "2", "--sn", "32", "--xcd-remap", "0"],
     "c3": ["--3d", "--dtype", "fp32", "--step", "2", "--temporal", "1", "--prefetch", "--bx", "66", "--by", "15", "--block-merge-x", "4", "--block-merge-y", "2", "--sn", "16", "--xcd-remap", "0"],
 }
-# N > 1 (slabs): the same kernel with ONE stream block per tile whenever the tiles alone fill the GPU -- C4 has
-# 1024/128 x 1024/32 = 256 tiles = one workgroup per CU: no z-halo planes are fetched twice and the launch has no tail
-# (128-plane view 0.186 ms vs 0.199 with 16-plane blocks, 256-plane view 0.380 vs 0.424, 512-plane view 0.758 vs 0.804;
-# on the full 1024-plane grid the long blocks drift apart and lose: profiles/r01_exp_r1zj_one_block_per_tile.log, r01_exp_r1zk_one_block_per_tile.log).
-# Fewer tiles than CUs (C3: 64): as many stream blocks per tile as it takes to cover the CUs.
+# N > 1 (z slabs of C4): the same fused kernel; slabs of 256 planes or fewer get 16-plane stream blocks.  One stream block
+# per tile (256 tiles = one workgroup per CU) is the fastest way to sweep a slab ALONE (128-plane view 0.186 ms vs 0.199,
+# 256: 0.380 vs 0.424, 512: 0.758 vs 0.804 -- profiles/r01_exp_r1zj_one_block_per_tile.log, r01_exp_r1zk_...), but its
+# workgroups hold every CU until the launch ends, so the RCCL send/recv kernel cannot start beside it: in the rehearsal
+# a rank of the 8-GPU run drops from 1200 to 1130 GStencil/s.  Short blocks retire every ~20 us and let it in.
 def slab_options(workload, world, weak=False):
     opts = list(TUNED[workload])
-    w = WORKLOADS[workload]
-    if w["ndim"] != 3 or weak or world < 2 or "--sn" not in opts:
-        return opts
-    import re
-    dims = dict((k, int(v)) for k, v in re.findall(r"\b([LMN])\s+(\d+)", open(w["stc"]).read()))
-    def val(name, default):
-        return int(opts[opts.index(name) + 1]) if name in opts else default
-    tiles = -(-dims["N"] // (val("--bx", 64) * val("--block-merge-x", 4))) * -(-dims["M"] // (val("--by", 4) * val("--block-merge-y", 1)))
-    zblocks = max(1, -(-256 // tiles))
-    opts[opts.index("--sn") + 1] = str(-(-(dims["L"] // world) // zblocks))
+    if workload == "c4" and world >= 4 and not weak:
+        opts[opts.index("--sn") + 1] = "16"
     return opts
 
 
