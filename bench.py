@@ -261,6 +261,7 @@ def main():
         run = (SelfNeighbourRun if rehearse else SlabRun)(torch, dist, (L, M, N) if w["ndim"] == 3 else (M, N), H, step, iters, prank, pworld, sweep, dev, tdt, every=args.exchange_every)
         g = torch.Generator(device=dev).manual_seed(1 + prank)
         run.A.copy_(torch.rand(run.A.shape, dtype=tdt, device=dev, generator=g))
+        torch.cuda.synchronize()     # the run's streams are not the one that filled A
         for _ in range(args.warmup):
             run.run()
         torch.cuda.synchronize()
