@@ -9,6 +9,9 @@ the metric is quoted on; 8 GiB for the two buffers, fits one GPU).  One "step" =
 reference's timed region (codegen.hpp:581-584): the ping-pong loop over the .stc's 4 time
 steps = 2*ceil(4/(2*step)) kernel launches.  N > 1: the same 1024^3 grid cut into z slabs,
 one process per GPU, RCCL halo exchange overlapped with the interior sweep (strong scaling).
+`python bench.py --gpus N` without a launcher starts its own N rank processes (spawn_ranks: children started
+before anything in this process touches HIP or imports torch); under `python -m torch.distributed.run` (RANK /
+WORLD_SIZE in the environment) it is one of the ranks.
 
 value      = grid-point updates of all ranks / max-over-ranks wall time, in GStencil/s
 roofline   = algorithmic bytes (2*sizeof(T) per grid point per launch)
@@ -30,6 +33,11 @@ WORKLOADS = {
     "c3": dict(stc=os.path.join(CFG, "c3_3d7pt_star_512.stc"), ndim=3, dtype="fp32", name="3d7pt_star 512^3 fp32 (BASELINE C3), iterations 4"),
     "c2": dict(stc=os.path.join(CFG, "c2_2d5pt_star_8192.stc"), ndim=2, dtype="fp32", name="2d5pt_star 8192^2 fp32 (BASELINE C2), iterations 4"),
     "c5": dict(stc=os.path.join(CFG, "c5_2d25pt_box_16384.stc"), ndim=2, dtype="fp64", name="2d25pt_box 16384^2 fp64 (BASELINE C5), iterations 4"),
+    # the reference's native precision (codegen.hpp:148: double only) on the BASELINE grids; 8192^2 and 512^3 are its own shipped sizes
+    # (benchmarks/2d5pt_star/2d5pt_star.stc:1-4, benchmarks/3d7pt_star/3d7pt_star.stc:1-5) -- SURVEY.md 8(f) rank 4
+    "c2f64": dict(stc=os.path.join(CFG, "c2_2d5pt_star_8192.stc"), ndim=2, dtype="fp64", name="2d5pt_star 8192^2 fp64 (reference precision and size), iterations 4"),
+    "c3f64": dict(stc=os.path.join(CFG, "c3_3d7pt_star_512.stc"), ndim=3, dtype="fp64", name="3d7pt_star 512^3 fp64 (reference precision and size), iterations 4"),
+    "c4f64": dict(stc=os.path.join(CFG, "c4_3d7pt_star_1024.stc"), ndim=3, dtype="fp64", name="3d7pt_star 1024^3 fp64 (reference precision), iterations 4"),
 }
 # tuned generator options per workload (found with drstencil_amd/tuner; logs under profiles/).
 # Headline for the 3D workloads: two time steps per launch with the reference's own --step 2 arithmetic
@@ -47,6 +55,10 @@ TUNED = {
     # exhaustive 2D searches, profiles/r01_tune_c2_exhaustive.txt / r01_tune_c5_exhaustive.txt (0.78 of the HBM peak each)
     "c2": ["--dtype", "fp32", "--bx", "128", "--by", "2", "--block-merge-x", "4", "--block-merge-y", "2", "--xcd-remap", "0"],
     "c5": ["--dtype", "fp64", "--bx", "64", "--by", "4", "--block-merge-x", "2", "--block-merge-y", "4", "--xcd-remap", "0"],
+    # fp64 (profiles/r01_tune_shipped.md: exhaustive searches at the reference sizes): the 2D tile of 2d5pt_star step 1; fused step 2 in 3D
+    "c2f64": ["--dtype", "fp64", "--bx", "128", "--by", "4", "--block-merge-x", "2", "--block-merge-y", "2", "--xcd-remap", "0"],
+    "c3f64": ["--3d", "--dtype", "fp64", "--step", "2", "--bx", "128", "--by", "4", "--block-merge-x", "2", "--block-merge-y", "2", "--sn", "32", "--xcd-remap", "2"],
+    "c4f64": ["--3d", "--dtype", "fp64", "--step", "2", "--bx", "128", "--by", "4", "--block-merge-x", "2", "--block-merge-y", "2", "--sn", "32", "--xcd-remap", "2"],
 }
 # the same workloads with one time step per launch: highest roofline fraction.  Full-row tiles (256 lanes x 4
 # points = N), 2 lane rows x 4 rows, 4-plane stream blocks, prefetch: the optimum of the exhaustive 1520-configuration
@@ -77,23 +89,36 @@ MIN_WARM_S = 0.25     # untimed warm-up continues (beyond --warmup steps) until 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak (MI355X_MICROARCH.md: 8.0 TB/s spec)
 
 
+def kernels():
+    """Every kernel bench.py can time: (id, workload, generator options).  __graft_entry__.build() prebuilds them and
+    tests/gpu_cases.py::FULL holds a full-size parity case for each (tests/test_capi_and_tuner.py checks that)."""
+    out = [("bench_%s_headline" % w, w, TUNED[w]) for w in sorted(TUNED)]
+    out += [("bench_%s_step1" % w, w, STEP1[w]) for w in sorted(STEP1)]
+    out += [("bench_%s_temporal2" % w, w, TEMPORAL2[w]) for w in sorted(TEMPORAL2)]
+    return out
+
+
 def kernel_arg_sets():
-    """Kernels bench.py needs; prebuilt by __graft_entry__.build()."""
-    return [TUNED[w] + [WORKLOADS[w]["stc"]] for w in ("c4", "c3", "c2", "c5")] + [STEP1[w] + [WORKLOADS[w]["stc"]] for w in ("c4", "c3")] + [TEMPORAL2[w] + [WORKLOADS[w]["stc"]] for w in ("c4", "c3")]
+    """Argument vectors of kernels(); prebuilt by __graft_entry__.build()."""
+    return [o + [WORKLOADS[w]["stc"]] for _, w, o in kernels()]
 
 
 def pmc_traffic(workload, option_string):
     """HBM bytes per launch of this exact workload + kernel configuration from the committed rocprofv3 PMC
-    passes (FETCH_SIZE x 2 + WRITE_SIZE, profiles/traffic_by_options.json); None when it was not profiled."""
+    passes (FETCH_SIZE x 2 + WRITE_SIZE, profiles/traffic_by_options.json): (bytes, where the number comes from), or
+    (None, why not) when this configuration was not profiled -- the counters cannot be read inside a timed run."""
+    path = os.path.join("profiles", "traffic_by_options.json")
     try:
-        m = json.load(open(os.path.join(ROOT, "profiles", "traffic_by_options.json")))
-        return m[workload][option_string]["traffic_bytes_per_launch"]
+        m = json.load(open(os.path.join(ROOT, path)))
+        e = m[workload][option_string]
+        return e["traffic_bytes_per_launch"], "%s [%s][%s] <- %s" % (path, workload, option_string, e.get("source", "?"))
     except Exception:
-        return None
+        return None, "no PMC passes committed for [%s][%s] in %s" % (workload, option_string, path)
 
 
-def cpu_baseline(workload, step, budget_s=15.0):
-    """Oracle (port) timed on the host cores on a bounded z/y-slab sample of the workload."""
+def cpu_baseline(workload, step, budget_s=15.0, host_slab=None):
+    """Oracle (port) timed on the host cores on a bounded z/y-slab sample of the workload: the first slices of the very
+    array the GPU loop started from (host_slab), or seeded random numbers of the same shape."""
     import numpy as np
     import oracle
     w = WORKLOADS[workload]
@@ -103,14 +128,17 @@ def cpu_baseline(workload, step, budget_s=15.0):
     if w["ndim"] == 3:
         Ls = min(L, 128)
         spec.set_dims(Ls, M, N)
-        sample = "%d x %d x %d z-slab of the %d^3 grid" % (Ls, M, N, L)
+        sample = "SAMPLE: %d x %d x %d z-slab of the %d^3 grid" % (Ls, M, N, L)
     else:
         Ms = min(M, 4096)
         spec.set_dims(1, Ms, N)
-        sample = "%d x %d y-slab" % (Ms, N)
+        sample = "SAMPLE: %d x %d y-slab of the %d x %d grid" % (Ms, N, M, N)
     dt = np.float32 if w["dtype"] == "fp32" else np.float64
-    rng = np.random.default_rng(1)
-    A = rng.random(spec.shape, dtype=dt)
+    if host_slab is not None and tuple(host_slab.shape) == tuple(spec.shape):
+        A = np.ascontiguousarray(host_slab, dtype=dt)
+        sample += " (the GPU run's own input)"
+    else:
+        A = np.random.default_rng(1).random(spec.shape, dtype=dt)
     B = np.zeros_like(A)
     h = spec.halo
     interior = 1
@@ -131,7 +159,68 @@ def cpu_baseline(workload, step, budget_s=15.0):
                 sample="%s, %d sweeps in %.1f s (OpenMP, %d threads)" % (sample, sweeps, el, oracle.threads()))
 
 
-def main():
+def verify_timed_kernel(torch, kern, workload, A, B, step, temporal):
+    """What bench.py timed is what the parity tests check: ONE launch of the timed kernel on the run's own input against
+    (1) the emitted gold kernel on the whole grid (the reference's --check path, codegen.hpp:591-627) and (2) the CPU oracle
+    on the first 2*Halo+12 slices.  Bit-exact, except temporal blocking (re-associated: 1e-6 relative fp32 / 1e-12 fp64).
+    A holds the input, B receives the output; returns (ok, details, host copy of the first <= 128 slices of A)."""
+    import numpy as np
+    import oracle
+    w = WORKLOADS[workload]
+    h = kern.info["halo"]
+    tol = 1e-6 if w["dtype"] == "fp32" else 1e-12
+    G = torch.zeros_like(A)
+    B.zero_()
+    kern.launch(A.data_ptr(), B.data_ptr())
+    kern.launch_gold(A.data_ptr(), G.data_ptr())
+    torch.cuda.synchronize()
+    inner = tuple(slice(h, d - h) for d in A.shape)
+    if temporal:
+        rel = float(((B[inner] - G[inner]).abs() / G[inner].abs().clamp_min(1e-30)).max())
+        gold_ok = rel <= tol
+    else:
+        rel = 0.0 if torch.equal(B, G) else float(((B[inner] - G[inner]).abs() / G[inner].abs().clamp_min(1e-30)).max())
+        gold_ok = torch.equal(B, G)
+    ring_ok = int(torch.count_nonzero(B)) == int(torch.count_nonzero(B[inner]))      # the ring of the output is never written
+    del G
+    nsl = min(A.shape[0], 2 * h + 12)
+    keep = min(A.shape[0], 128 if w["ndim"] == 3 else 4096)
+    host = A[:keep].cpu().numpy()
+    sub = np.ascontiguousarray(host[:nsl])
+    dst = np.zeros_like(sub)
+    spec = oracle.Spec(w["stc"], w["ndim"], step)
+    if w["ndim"] == 3:
+        spec.set_dims(nsl, A.shape[1], A.shape[2])
+    else:
+        spec.set_dims(1, nsl, A.shape[1])
+    oracle.sweep(spec, sub, dst, contract=1)
+    got = B[h:nsl - h].cpu().numpy()
+    ref = dst[h:nsl - h]
+    if temporal:
+        sel = (slice(None),) + tuple(slice(h, d - h) for d in got.shape[1:])
+        orel = float(np.max(np.abs(got[sel].astype(np.float64) - ref[sel]) / np.maximum(np.abs(ref[sel]), 1e-30)))
+        oracle_ok = orel <= tol
+    else:
+        oracle_ok = bool(np.array_equal(got, ref))
+        orel = 0.0 if oracle_ok else float(np.max(np.abs(got.astype(np.float64) - ref) / np.maximum(np.abs(ref), 1e-30)))
+    return (gold_ok and oracle_ok and ring_ok), {
+        "vs_gold_kernel_full_grid": {"ok": bool(gold_ok), "max_rel": rel, "bit_exact_required": not temporal},
+        "vs_cpu_oracle_slab": {"ok": bool(oracle_ok), "max_rel": orel, "slices": int(nsl), "bit_exact_required": not temporal},
+        "ring_untouched": bool(ring_ok), "tolerance": 0.0 if not temporal else tol}, host
+
+
+def device_info(torch, dev):
+    """Which MI355X this was (boxes differ by a few per cent in memory clocks): name, uuid, CU count -- from the HIP device
+    properties, no child process."""
+    try:
+        p = torch.cuda.get_device_properties(dev)
+        return {"name": p.name, "arch": getattr(p, "gcnArchName", None), "uuid": str(getattr(p, "uuid", "")), "compute_units": p.multi_processor_count,
+                "total_memory_GiB": round(p.total_memory / 2**30, 1)}
+    except Exception as e:       # diagnostics only
+        return {"error": repr(e)}
+
+
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=40)
@@ -143,11 +232,79 @@ def main():
                     help="N > 1: strong = the workload's grid cut into N slabs (default, SURVEY 8e); weak = every rank holds a full-size slab (grid L*N planes)")
     ap.add_argument("--exchange-every", type=int, default=0, choices=[0, 1, 2],
                     help="N > 1: launches per halo exchange (2: ghost planes twice as wide, one exchange per ping-pong pair; "
-                         "0 = multigpu.choose_exchange_every)")
+                         "0 = measured during warm-up on this machine, multigpu.measure_exchange_every)")
     ap.add_argument("--headline-only", action="store_true", help="skip the side measurements (profiling runs: one dr_ kernel in the trace)")
-    args = ap.parse_args()
+    ap.add_argument("--no-verify", action="store_true", help="skip the post-loop comparison of the timed kernel with the gold kernel and the oracle")
+    ap.add_argument("--n1-value", type=float, default=None, help="N > 1: the N = 1 value of the same workload; the line then carries value / (N * n1) as efficiency_vs_n1")
+    ap.add_argument("--prebuild-only", action="store_true", help="build (or find cached) every kernel the run needs for all --gpus ranks, then exit; no GPU is touched")
+    return ap.parse_args(argv)
 
-    import torch
+
+def child_command(argv):
+    """Command line of one rank process.  DRS_BENCH_CHILD (a JSON list) replaces `python bench.py` -- the CPU test uses it
+    to record what would be started."""
+    stub = os.environ.get("DRS_BENCH_CHILD")
+    return (json.loads(stub) if stub else [sys.executable, os.path.abspath(__file__)]) + list(argv)
+
+
+def rank_env(rank, world, port, base=None):
+    env = dict(os.environ if base is None else base)
+    env.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), LOCAL_WORLD_SIZE=str(world),
+               MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+               DRS_NO_COMPILE="1")      # every kernel was prebuilt by the parent's prebuild child: a rank never starts hipcc
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return env
+
+
+def spawn_ranks(args, argv):
+    """`python bench.py --gpus N` as a plain command: start N rank processes (one per GPU, RANK / LOCAL_RANK / WORLD_SIZE /
+    MASTER_* set), relay rank 0's JSON line, return the worst exit code.  This process imports neither torch nor the HIP
+    runtime: a launcher hop is only legal before any GPU call.  Kernels are built once, by a child, before the ranks start."""
+    import socket
+    import subprocess
+    n = args.gpus
+    rc = subprocess.call(child_command(list(argv) + ["--prebuild-only"]))
+    if rc != 0:
+        print("bench.py: prebuild failed (rc %d)" % rc, file=sys.stderr)
+        return rc or 1
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = [subprocess.Popen(child_command(argv), env=rank_env(r, n, port), stdout=subprocess.PIPE if r == 0 else sys.stderr, text=(r == 0)) for r in range(n)]
+    worst = 0
+    try:
+        alive = set(range(n))
+        while alive:
+            for r in sorted(alive):
+                code = procs[r].poll()
+                if code is None:
+                    continue
+                alive.discard(r)
+                worst = worst or code
+                if code != 0:            # a rank died: the others would wait for it in RCCL for ever
+                    for q in alive:
+                        procs[q].terminate()
+            time.sleep(0.05)
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    out = procs[0].stdout.read() if procs[0].stdout else ""
+    sys.stdout.write(out)
+    sys.stdout.flush()
+    return worst
+
+
+def main(argv=None):
+    argv = list(sys.argv[1:] if argv is None else argv)
+    args = parse_args(argv)
+    rehearse = os.environ.get("DRS_REHEARSE")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ and not rehearse and not args.prebuild_only:
+        raise SystemExit(spawn_ranks(args, argv))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if not args.prebuild_only and not rehearse and world != args.gpus:       # decided before anything touches the GPU
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+
     import drstencil_amd as drs
 
     if not os.path.exists(drs.LIB_PATH):
@@ -158,14 +315,15 @@ def main():
             fcntl.flock(lk, fcntl.LOCK_EX)
             if not os.path.exists(drs.LIB_PATH):
                 subprocess.check_call(["make", "-C", os.path.join(ROOT, "drstencil_amd", "csrc")], stdout=subprocess.DEVNULL)
-    world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     # DRS_REHEARSE="r/R": run the N > 1 code path as middle rank r of R on ONE GPU (process group of size 1, the rank is
     # its own neighbour) -- a rehearsal of the multi-GPU branch where only one GPU exists; the line says so
-    rehearse = os.environ.get("DRS_REHEARSE")
     prank, pworld = (int(x) for x in rehearse.split("/")) if rehearse else (rank, world)
-    assert not rehearse or world == 1
+    if rehearse and world != 1:
+        raise SystemExit("bench.py: DRS_REHEARSE runs in ONE process")
+    if args.prebuild_only:
+        pworld = max(args.gpus, pworld)
     # Generate + compile (or find cached) every kernel BEFORE HIP is initialised: a process
     # that has touched the GPU must not fork/exec the compiler.
     w = WORKLOADS[args.workload]
@@ -189,8 +347,14 @@ def main():
         from drstencil_amd.multigpu import HipSweep, SelfNeighbourRun, SlabPlan, SlabRun, measure_exchange_every
         auto_every = args.exchange_every == 0      # decided after the process group is up, from measured sweep / exchange times
         sweep = HipSweep(w["stc"], opts, os.path.join(ROOT, "drstencil_amd", "_kcache"))
-        for ev in ((1, 2) if auto_every else (args.exchange_every,)):      # both modes' kernels: built (cache hits) before HIP is up
-            sweep.prebuild(SlabPlan(L if w["ndim"] == 3 else M, H, pworld, prank, ev))
+        for r in (range(pworld) if args.prebuild_only else (prank,)):
+            for ev in ((1, 2) if auto_every else (args.exchange_every,)):      # both modes' kernels: built (cache hits) before HIP is up
+                sweep.prebuild(SlabPlan(L if w["ndim"] == 3 else M, H, pworld, r, ev))
+    if args.prebuild_only:
+        print("bench.py: kernels for %d rank(s) of %s are in the cache" % (pworld, args.workload), file=sys.stderr)
+        return
+    os.environ["DRS_NO_COMPILE"] = "1"      # from here on a cache miss is an error, not a hipcc child of a GPU process
+    import torch
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the product path has no CPU fallback)")
     torch.cuda.set_device(local_rank)
@@ -202,7 +366,6 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29541")
         from drstencil_amd.multigpu import nccl_options
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev, pg_options=nccl_options(dist))
-    assert world == args.gpus or world == 1 and args.gpus == 1, "launch with torch.distributed.run for --gpus > 1"
 
     tdt = torch.float32 if w["dtype"] == "fp32" else torch.float64
     esz = 4 if w["dtype"] == "fp32" else 8
@@ -254,6 +417,11 @@ def main():
                     "roofline_frac": by * n1 / (ms1 * 1e-3) / 1e9 / HBM_PEAK_GBS}
         step1 = side(kern1, STEP1[args.workload], 16) if kern1 is not None else None
         fused2 = side(kernf, TEMPORAL2[args.workload], 32) if kernf is not None else None
+        verified, verification, host_slab = None, None, None
+        if not args.no_verify:
+            g = torch.Generator(device=dev).manual_seed(1)
+            A.copy_(torch.rand(shape, dtype=tdt, device=dev, generator=g))      # the input the timed loop started from
+            verified, verification, host_slab = verify_timed_kernel(torch, kern, args.workload, A, B, step, kinfo.get("stages", 1) > 1)
     else:
         if auto_every:
             args.exchange_every, calibration = measure_exchange_every(torch, dist, (L, M, N) if w["ndim"] == 3 else (M, N), H, prank, pworld, sweep, dev, tdt,
@@ -284,6 +452,10 @@ def main():
         torch.cuda.synchronize()
         el = time.perf_counter() - t0
         ev_ms = e0.elapsed_time(e1)
+        mine = torch.tensor([el * 1e3 / max(args.steps, 1)], dtype=torch.float64, device=dev)
+        per_rank = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(per_rank, mine)
+        rank_ms_per_step = [float(x[0]) for x in per_rank]
         t = torch.tensor([el, ev_ms], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         el, ev_ms = float(t[0]), float(t[1])
@@ -291,6 +463,7 @@ def main():
         kres = sweep.kernel(run.plan.interior[1] - run.plan.interior[0]).resources
         parallelism = "%s-slab x%d%s, RCCL send/recv halo every %d launch(es), overlapped" % ("z" if w["ndim"] == 3 else "y", pworld, " (weak: grid %s)" % "x".join(str(d) for d in ((L, M, N) if w["ndim"] == 3 else (M, N))) if weak else "", args.exchange_every)
         step1 = fused2 = None
+        verified, verification, host_slab = None, None, None     # the slab kernels' parity is tests/test_gpu_parity.py::test_c4_slab_views_at_full_size
 
     if rank == 0:
         total_launches = launches_per_step * args.steps
@@ -304,27 +477,34 @@ def main():
         alg_bytes = 2.0 * esz * npoints / max(pworld, 1)    # per launch per GPU
         avg_launch_s = (ev_ms * 1e-3) / total_launches
         achieved = alg_bytes / avg_launch_s / 1e9
+        traffic, traffic_source = pmc_traffic(args.workload, " ".join(opts)) if pworld == 1 else (None, "single-GPU PMC passes only")
         out = {
             "metric": "GStencil/s (grid-point updates/s), 3d7pt_star" if args.workload in ("c3", "c4") else "GStencil/s (grid-point updates/s)",
             "value": value, "unit": "GStencil/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "warmup_steps_run": args.warmup + warm_extra,
             "ms_per_step": el * 1e3 / args.steps, "higher_is_better": True, "scaling": "weak" if weak else "strong",
-            "vs_baseline": None, "dtype": "f32" if w["dtype"] == "fp32" else "f64", "data": "synthetic",
+            "vs_baseline": None, "dtype": "f32" if w["dtype"] == "fp32" else "f64", "data": "synthetic", "verified": verified,
             "config": {"workload": w["name"], "generator_options": " ".join(opts), "step": step,
                        "launches_per_step": launches_per_step, "parallelism": parallelism,
                        "kernel": "dr_" + kinfo["name"], "threads": kinfo["threads"], "lds_bytes": kinfo["lds_bytes"],
                        "vgprs": kres.get("vgprs"), "agprs": kres.get("agprs"), "scratch_bytes_per_lane": kres.get("scratch_bytes_per_lane"),
                        "occupancy_waves_per_simd": kres.get("occupancy_waves_per_simd")},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(args.workload, " ".join(opts)) if pworld == 1 else None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
                          "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": avg_launch_s * 1e3},
+            "verification": verification,
+            "device": device_info(torch, dev),
         }
+        if pworld > 1:
+            out["rank_ms_per_step"] = rank_ms_per_step
+            if args.n1_value:
+                out["efficiency_vs_n1"] = value / (pworld * args.n1_value)     # strong and weak alike: N GPUs against N times one GPU's rate
         if calibration:
             out["config"]["exchange_calibration"] = calibration      # measured on this machine during warm-up (multigpu.measure_exchange_every)
         out["step1_kernel"] = step1                 # one time step per launch: highest roofline fraction
         out["temporal_step2_kernel"] = fused2       # on-chip temporal blocking (2 stages): equal to the headline up to rounding
         if not args.no_cpu_baseline and pworld == 1:
             sys.path.insert(0, ROOT)
-            out["cpu_baseline"] = cpu_baseline(args.workload, step)
+            out["cpu_baseline"] = cpu_baseline(args.workload, step, host_slab=host_slab)
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out), flush=True)

@@ -10,6 +10,8 @@
 #include <sys/types.h>
 #include <unistd.h>
 
+#include <algorithm>
+#include <cctype>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -24,6 +26,8 @@ using namespace drs;
 struct drs_spec {
     Stencil st;
 };
+
+static bool g_launched = false;   // a kernel has been launched through this library: HIP is up, hipcc may no longer be started
 
 struct drs_kernel {
     void *dl = nullptr;
@@ -165,17 +169,46 @@ static long remark_value(const std::string &block, const char *label) {
     return at == std::string::npos ? -1 : strtol(block.c_str() + at + 1, nullptr, 10);
 }
 
-// Resource use of dr_<name> from hipcc's -Rpass-analysis=kernel-resource-usage remarks, as JSON.
-static std::string resources_json(const std::string &hipcc_output, const std::string &kernel) {
-    size_t at = hipcc_output.find("Function Name: dr_" + kernel);
-    if (at == std::string::npos) return "{}";
+// Resource use of one kernel (dr_<name> or dr2_<name>) from hipcc's -Rpass-analysis=kernel-resource-usage remarks: the
+// text of its remark block, or "" when the compiler printed none for it.
+static std::string remark_block(const std::string &hipcc_output, const std::string &symbol) {
+    // "Function Name: dr_x" must not match "Function Name: dr_x_suffix": the name ends the remark's line
+    size_t at = 0;
+    const std::string tag = "Function Name: " + symbol;
+    for (;;) {
+        at = hipcc_output.find(tag, at);
+        if (at == std::string::npos) return "";
+        const char c = at + tag.size() < hipcc_output.size() ? hipcc_output[at + tag.size()] : '\n';
+        if (!(isalnum((unsigned char)c) || c == '_')) break;
+        at += tag.size();
+    }
     size_t end = hipcc_output.find("Function Name:", at + 14);
-    const std::string b = hipcc_output.substr(at, end == std::string::npos ? std::string::npos : end - at);
-    char buf[512];
+    return hipcc_output.substr(at, end == std::string::npos ? std::string::npos : end - at);
+}
+
+// Resource use as JSON: dr_<name>, and with --pair-launch the maximum over dr_<name> and dr2_<name> (the pair kernel is
+// the one middle ranks of a slab run launch).  Any field the report lacks is -1; `parsed` says whether every field of
+// every kernel was found -- the caller refuses to load a kernel it could not verify.
+static std::string resources_json(const std::string &hipcc_output, const std::string &kernel, bool pair, bool *parsed) {
+    static const char *labels[] = {"VGPRs:", "AGPRs:", "TotalSGPRs:", "ScratchSize [bytes/lane]:", "SGPRs Spill:", "VGPRs Spill:", "Occupancy [waves/SIMD]:", "LDS Size [bytes/block]:"};
+    long v[8];
+    bool ok = true;
+    for (int i = 0; i < 8; i++) v[i] = -1;
+    for (int which = 0; which < (pair ? 2 : 1); which++) {
+        const std::string b = remark_block(hipcc_output, (which ? "dr2_" : "dr_") + kernel);
+        if (b.empty()) { ok = false; continue; }
+        for (int i = 0; i < 8; i++) {
+            const long x = remark_value(b, labels[i]);
+            if (x < 0) ok = false;
+            if (i == 6) v[i] = (which == 0 || v[i] < 0) ? x : std::min(v[i], x);   // occupancy: the lower one
+            else v[i] = std::max(v[i], x);
+        }
+    }
+    if (parsed) *parsed = ok;
+    char buf[640];
     snprintf(buf, sizeof buf, "{\"vgprs\": %ld, \"agprs\": %ld, \"sgprs\": %ld, \"scratch_bytes_per_lane\": %ld, \"sgpr_spill\": %ld, "
-                              "\"vgpr_spill\": %ld, \"occupancy_waves_per_simd\": %ld, \"lds_bytes\": %ld}",
-             remark_value(b, "VGPRs:"), remark_value(b, "AGPRs:"), remark_value(b, "TotalSGPRs:"), remark_value(b, "ScratchSize [bytes/lane]:"),
-             remark_value(b, "SGPRs Spill:"), remark_value(b, "VGPRs Spill:"), remark_value(b, "Occupancy [waves/SIMD]:"), remark_value(b, "LDS Size [bytes/block]:"));
+                              "\"vgpr_spill\": %ld, \"occupancy_waves_per_simd\": %ld, \"lds_bytes\": %ld, \"kernels_reported\": \"%s\", \"verified\": %d}",
+             v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7], pair ? "dr_+dr2_" : "dr_", ok ? 1 : 0);
     return buf;
 }
 
@@ -204,13 +237,26 @@ drs_kernel *drs_kernel_build(int argc, const char *const *argv, const char *cach
     const char *hipcc_env = getenv("DRS_HIPCC");
     const std::string hipcc = hipcc_env ? hipcc_env : "/opt/rocm/bin/hipcc";
     // the resource-usage remarks (registers, scratch, LDS per kernel) only add diagnostics; they are parsed below
-    const std::string flags = "-O3 --offload-arch=gfx950 -std=c++17 -ffp-contract=off -shared -fPIC -DDRS_PLUGIN -Rpass-analysis=kernel-resource-usage";
-    // the key covers everything that determines the binary except the banner lines
+    std::string flags = "-O3 --offload-arch=gfx950 -std=c++17 -ffp-contract=off -shared -fPIC -DDRS_PLUGIN -Rpass-analysis=kernel-resource-usage";
+    for (auto &f : r.opt.cc_opts) flags += " " + shq(f);     // --cc-opt: per-kernel compiler flags (part of the cache key below)
+    // the key covers everything that determines the binary except the banner lines.  The file stem is a readable prefix of
+    // the kernel name plus the FULL 64-bit hash: the hash is never truncated, whatever the length of the .stc's name
     std::string body = r.source.substr(r.source.find("#include"));
-    char key[64];
-    snprintf(key, sizeof key, "%s_%016llx", r.plan.name.c_str(), fnv1a(body + flags + "|build-policy-2")   /* bump when the compile/verify policy below changes */);
+    char hex[24];
+    snprintf(hex, sizeof hex, "%016llx", fnv1a(body + flags + "|build-policy-3")   /* bump when the compile/verify policy below changes */);
+    const std::string key = r.plan.name.substr(0, 40) + "_" + hex;
     const std::string src = cdir + "/" + key + ".hip", so = cdir + "/" + key + ".so", res = cdir + "/" + key + ".res";
     if (!file_exists(so) || !file_exists(res)) {
+        // The compiler is a child process.  A process that has initialised HIP must not start one on the MI355X pool (and
+        // under `rocprofv3 --pmc` the GPU is initialised before main), so a cache miss is an ERROR once this process has
+        // launched a kernel through this library, or whenever DRS_NO_COMPILE=1 (set by profiling scripts and by ranks
+        // after their prebuild): build every kernel first.
+        const char *nocc = getenv("DRS_NO_COMPILE");
+        if (g_launched || (nocc && nocc[0] == '1')) {
+            if (log) *log = dup_cstr("drstencil: kernel " + key + " is not in the cache (" + cdir + ") and this process may not run hipcc any more (" +
+                                     (g_launched ? "it has already launched a kernel" : "DRS_NO_COMPILE=1") + "): build every kernel before the first launch\n");
+            return nullptr;
+        }
         char tmpl[64];
         snprintf(tmpl, sizeof tmpl, ".%d.tmp", (int)getpid());
         const std::string tsrc = src + tmpl + ".hip", tso = so + tmpl;
@@ -226,16 +272,17 @@ drs_kernel *drs_kernel_build(int argc, const char *const *argv, const char *cach
         // round-1 fuzz found miscompiled sat in that path, and both are correct when either that spilling or the
         // scheduler's "unclustered high register pressure reschedule" stage is off (profiles/r01_fuzz_parity_1200.txt).
         // Such kernels are rebuilt without that stage; kernels that stay within the VGPRs (all bench kernels) are not
-        // touched by it (it costs the 2D 25-point kernel 5 %).
-        std::string report = resources_json(out, r.plan.name);
-        if (remark_value(report, "\"agprs\":") > 0) {
+        // touched by it (it costs the 2D 25-point kernel 5 %).  With --pair-launch the rule looks at dr2_<name> as well.
+        bool parsed = false;
+        std::string report = resources_json(out, r.plan.name, r.opt.pair_launch != 0, &parsed);
+        if (parsed && remark_value(report, "\"agprs\":") > 0) {
             out = run_capture(shq(hipcc) + " " + flags + " -mllvm -amdgpu-disable-unclustered-high-rp-reschedule -I" + shq(support) + " -o " + shq(tso) + " " + shq(tsrc), &rc);
             if (rc != 0 || !file_exists(tso)) {
                 if (log) *log = dup_cstr("hipcc failed (" + std::to_string(rc) + "):\n" + out);
                 unlink(tso.c_str());
                 return nullptr;
             }
-            report = resources_json(out, r.plan.name);
+            report = resources_json(out, r.plan.name, r.opt.pair_launch != 0, &parsed);
             report.insert(report.size() - 1, ", \"rebuilt_without_high_rp_reschedule\": 1");
         }
         const std::string tres = res + tmpl;
@@ -244,9 +291,18 @@ drs_kernel *drs_kernel_build(int argc, const char *const *argv, const char *cach
         rename(tres.c_str(), res.c_str());
         rename(tso.c_str(), so.c_str());
     }
+    const std::string resources = read_text(res);
+    // Both rules above and below FAIL CLOSED: a kernel whose resource report could not be read (another compiler's remark
+    // format, a DRS_HIPCC wrapper that swallows stderr) was never checked for the AGPR / scratch paths the round-1 fuzz
+    // found miscompiled, so it is not loaded unless DRS_ALLOW_UNVERIFIED=1.
+    const char *unv = getenv("DRS_ALLOW_UNVERIFIED");
+    if (remark_value(resources, "\"verified\":") != 1 && !(unv && unv[0] == '1')) {
+        if (log) *log = dup_cstr("drstencil: no compiler resource report for dr_" + r.plan.name + (r.opt.pair_launch ? " / dr2_" + r.plan.name : "") + " (" + resources +
+                                 "): the kernel cannot be checked for AGPR spilling and scratch use, so it is not loaded (DRS_ALLOW_UNVERIFIED=1 loads it anyway)\n");
+        return nullptr;
+    }
     // A kernel that spills to scratch has outgrown the 512 registers a lane can have: it is slow, and it is where the
     // two miscompiled kernels of the round-1 parity fuzz came from (profiles/r01_fuzz_parity_1200.txt), so it is refused.
-    const std::string resources = read_text(res);
     const long scratch = remark_value(resources, "\"scratch_bytes_per_lane\":");
     const char *allow = getenv("DRS_ALLOW_SCRATCH");
     if (scratch > 0 && !(allow && allow[0] == '1')) {
@@ -254,6 +310,11 @@ drs_kernel *drs_kernel_build(int argc, const char *const *argv, const char *cach
                                  "-- the configuration exceeds the register file: use a smaller tile (--by, --block-merge-y), --prefetch-depth 1 or a "
                                  "256-lane workgroup (DRS_ALLOW_SCRATCH=1 loads it anyway)\n");
         return nullptr;
+    }
+    // kernels with barriers removed (--debug-drop-barrier: timing experiments, wrong results) load only when asked for
+    if (r.opt.debug_drop_barrier) {
+        const char *ex = getenv("DRS_EXPERIMENTS");
+        if (!(ex && ex[0] == '1')) { if (log) *log = dup_cstr("drstencil: --debug-drop-barrier kernels compute wrong results; they load only with DRS_EXPERIMENTS=1\n"); return nullptr; }
     }
     void *dl = dlopen(so.c_str(), RTLD_NOW | RTLD_LOCAL);
     if (!dl) { if (log) *log = dup_cstr(std::string("dlopen failed: ") + dlerror() + "\n"); return nullptr; }
@@ -285,18 +346,22 @@ const char *drs_kernel_path(const drs_kernel *k) { return k->path.c_str(); }
 const char *drs_kernel_resources(const drs_kernel *k) { return k->resources.c_str(); }
 
 int drs_kernel_launch(drs_kernel *k, const void *d_in, void *d_out, void *stream) {
+    g_launched = true;
     return k->launch(d_in, d_out, (hipStream_t)stream);
 }
 int drs_kernel_launch_pair(drs_kernel *k, const void *d_in0, void *d_out0, const void *d_in1, void *d_out1, void *stream) {
     if (!k->launch_pair) return -2;      // the kernel was not generated with --pair-launch 1
+    g_launched = true;
     return k->launch_pair(d_in0, d_out0, d_in1, d_out1, (hipStream_t)stream);
 }
 int drs_kernel_launch_gold(drs_kernel *k, const void *d_in, void *d_out, void *stream) {
+    g_launched = true;
     return k->launch_gold(d_in, d_out, (hipStream_t)stream);
 }
 
 int drs_kernel_run(drs_kernel *k, void *d_a, void *d_b, int iterations, int gold, void *stream) {
     auto fn = gold ? k->launch_gold : k->launch;
+    g_launched = true;
     int n = 0;
     for (int t = 0; t < iterations; t += 2 * k->step) {
         if (fn(d_a, d_b, (hipStream_t)stream) != 0) return -1;
@@ -308,6 +373,7 @@ int drs_kernel_run(drs_kernel *k, void *d_a, void *d_b, int iterations, int gold
 
 int drs_kernel_run_timed(drs_kernel *k, void *d_a, void *d_b, int iterations, int warmup, void *stream, float *ms) {
     hipStream_t s = (hipStream_t)stream;
+    g_launched = true;
     for (int i = 0; i < warmup; i++)
         if (k->launch(d_a, d_b, s) != 0) return -1;
     hipEvent_t e0, e1;

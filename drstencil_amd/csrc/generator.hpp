@@ -74,9 +74,15 @@ MI355X options:
 
 --dtype <fp32|fp64>     Element type (fp64 by default, as the reference).
 --xrim <lds|dpp>        x halo inside a wavefront by DPP wave shifts (default) or through LDS.
---schedule <scatter|window>  scatter (default): every arriving plane adds its taps to the
-                        partial sums of the output planes in flight (carried in VGPRs);
-                        window: keep a rotating register window per resident plane.
+--schedule <scatter|reuse|window>  How reuse along the streamed dimension is split between source planes kept on chip and
+                        partial sums carried in VGPRs (results never depend on it):
+                        scatter (default without --dist): nothing retained, every arriving plane adds its taps to the partial
+                        sums of all output planes in flight;
+                        reuse (default with --dist d): the reference's split for that dist -- `Range` source planes stay
+                        resident in register windows, partial sums are carried over the remaining planes; a retained
+                        plane's in-plane neighbours are kept in registers when that plane has at least --merge-forward
+                        in-plane taps, else re-read from LDS when they are due;
+                        window: every contributing plane resident, nothing carried.
 --temporal <0|1>        With --step n > 1: run the one-step stencil n times on chip (temporal blocking,
                         intermediate planes never leave the CU) instead of the fused stencil.
 --prefetch-depth <n>    With --prefetch: planes in flight ahead of the one being summed (n+1 register sets; default 3 (fp32) /
@@ -84,6 +90,13 @@ MI355X options:
 --pair-launch <0|1>     Also emit dr2_<name>(in0, out0, in1, out1): the same sweep over two buffer pairs in one launch.
 --exact-y <0|1>         1 (default for single-stage kernels): the y halo rows of the source plane are fetched by the halo loader
                         lanes, so every tile row is owned; 0: overlapped tiles (tile rows include the halo).
+--uniform-loads <0|1|2> With --prefetch: 0 (default) plane loads under `if (more planes)`; 1 issued unconditionally (past the
+                        block's last plane they re-read it); 2 unconditionally through a buffer window that closes past it.
+                        1 and 2 leave no vector-memory instruction under a branch: exact s_waitcnt vmcnt(N) pipelining.
+--store-mask <branch|buffer>  branch (default): guarded global stores; buffer: buffer stores whose per-lane offset is out of
+                        range where the lane must not store (no branch).
+--drain <0|1|2>         s_waitcnt vmcnt(0) before every plane's prefetch loads (1) or before its LDS staging (2).
+--cc-opt <flag>         Extra hipcc flag for this kernel (repeatable), e.g. --cc-opt -fno-slp-vectorize.
 --clamp-loads <0|1>     1 (default): branch-free loads -- lanes outside the grid read the plane origin (their
                         values never reach a stored output); 0: loads under per-lane guards.
 --halo-spread <0|1>     Spread the halo loader tasks over all wavefronts (default 0: the first lanes take them).
@@ -142,7 +155,7 @@ inline GenResult generate(const std::vector<std::string> &args /* argv[1..] */) 
         // ---- additive options
         else if (a == "--dtype") { if (!str_opt(o.dtype)) break; }
         else if (a == "--xrim") { if (!str_opt(o.xrim)) break; }
-        else if (a == "--schedule") { if (!str_opt(o.schedule)) break; }
+        else if (a == "--schedule") { if (!str_opt(o.schedule)) break; o.schedule_set = true; }
         else if (a == "--exact-y") { if (!int_opt(o.exact_y, nullptr)) break; }
         else if (a == "--xedge-select") { if (!int_opt(o.xedge_select, nullptr)) break; }
         else if (a == "--debug-drop-barrier") { if (!int_opt(o.debug_drop_barrier, nullptr)) break; }
@@ -153,6 +166,10 @@ inline GenResult generate(const std::vector<std::string> &args /* argv[1..] */) 
         else if (a == "--prefetch-auto") { if (!int_opt(o.prefetch_auto, nullptr)) break; }
         else if (a == "--prefetch-depth") { if (!int_opt(o.prefetch_depth, nullptr)) break; }
         else if (a == "--temporal") { if (!int_opt(o.temporal, nullptr)) break; }
+        else if (a == "--drain") { if (!int_opt(o.drain, nullptr)) break; }
+        else if (a == "--uniform-loads") { if (!int_opt(o.uniform_loads, nullptr)) break; }
+        else if (a == "--store-mask") { if (!str_opt(o.store_mask)) break; }
+        else if (a == "--cc-opt") { std::string f; if (!str_opt(f)) break; o.cc_opts.push_back(f); }
         else if (a == "--lazy-rims") { if (!int_opt(o.lazy_rims, nullptr)) break; }
         else if (a == "--xcd-remap") { if (!int_opt(o.xcd_remap, nullptr)) break; }
         else if (a == "--nt-store") { if (!int_opt(o.nt_store, nullptr)) break; }
@@ -164,8 +181,11 @@ inline GenResult generate(const std::vector<std::string> &args /* argv[1..] */) 
     }
     if (illegal_exit) return res;
     if (o.dtype != "fp32" && o.dtype != "fp64") { res.messages += "Illegal input.\n"; res.exit_code = 255; return res; }
-    if (o.schedule != "scatter" && o.schedule != "window") { res.messages += "Illegal input.\n"; res.exit_code = 255; return res; }
+    // an explicit --dist selects the reference's kind of reuse: `Range` source planes resident, the rest carried as partial sums
+    if (!o.schedule_set && o.dist != 0) o.schedule = "reuse";
+    if (o.schedule != "scatter" && o.schedule != "window" && o.schedule != "reuse") { res.messages += "Illegal input.\n"; res.exit_code = 255; return res; }
     if (o.xrim != "lds" && o.xrim != "dpp") { res.messages += "Illegal input.\n"; res.exit_code = 255; return res; }
+    if (o.store_mask != "buffer" && o.store_mask != "branch") { res.messages += "Illegal input.\n"; res.exit_code = 255; return res; }
     if (o.step < 1) { res.messages += "Illegal input.\n"; res.exit_code = 255; return res; }
 
     const std::string &stcfile = arg(argc - 1);

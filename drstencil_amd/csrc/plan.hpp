@@ -17,10 +17,15 @@
 //                       unrolled by a multiple of Range so register rotation is pure
 //                       renaming)
 //   --prefetch          software prefetch of the next plane into VGPRs across the barrier
-//   --dist/--merge-forward  accepted and validated like the reference (they select the
-//                       forward/backward partition reported as Range/Dist); the CDNA4
-//                       "scatter" schedule is that data-reuse idea with every partial sum
-//                       carried in registers, so they do not change the emitted arithmetic
+//   --dist d            the reference's data-reuse distance (drstencil.hpp:198-259): it fixes `Range`, the number of source
+//                       planes the reference keeps in shared memory, the rest of the reuse going through partial sums in
+//                       `out` (atomicAdd).  Here an explicit --dist selects --schedule reuse: `Range` planes stay resident in
+//                       register windows and partial sums are carried in VGPRs over the other R - Range planes
+//                       (emit_hip.hpp: carry()); without --dist everything is carried (scatter).  Different legal --dist
+//                       values give different kernels and identical results.
+//   --merge-forward t   reference: forward sets smaller than t are folded back into the backward set.  Here, per retained
+//                       plane: fewer in-plane taps than t -> its neighbours are re-read from LDS when due ("folded into the
+//                       window read"), else read on arrival and carried in registers.
 //   --step n            fused stencil (exact reference arithmetic) or, with --temporal 1,
 //                       n on-chip applications of the one-step stencil (temporal blocking)
 #pragma once
@@ -72,7 +77,25 @@ struct GenOptions {
                                  // 3 (fp32) / 2 (fp64) for fused multi-step 3D kernels (their wide halo leaves one resident workgroup per CU and
                                  // too few bytes in flight: 1.66 -> 1.56 ms on a slow-memory device, +1 % on a fast one), else 1
     int temporal = 0;            // step > 1: apply the one-step stencil `step` times on chip instead of the fused stencil
-    std::string schedule = "scatter";  // scatter: partial sums carried in VGPRs; window: rotating register windows
+    // Memory-path knobs of the streaming loop.  Defaults = the round-1 form, which the round-2 measurements could not beat
+    // (profiles/r02_exp_r2a_vmcnt_pipeline.log, r02_exp_r2b_memory_path.log; DESIGN.md section 3 "vmcnt"): with guarded loads and
+    // stores the compiler cannot count the vector-memory operations in flight and drains them (s_waitcnt vmcnt(0)) every plane;
+    // an exactly counted pipeline (uniform loads + buffer-masked stores) keeps 3-4 planes in flight and is 1-10 % SLOWER, because
+    // buffer stores cost 6 % (50 % where a quarter of the lanes is masked) and the per-plane drain itself is worth 3 %.
+    int drain = 0;               // 1: s_waitcnt vmcnt(0) before the prefetch loads of every plane are issued (a workgroup's reads and writes
+                                 // never overlap); 2: at the top of the iteration, before the staged plane is written to LDS; 0: none
+    int uniform_loads = 0;       // --prefetch: 0: plane loads under `if (the block still needs planes)`; 1: issued unconditionally (past the
+                                 // block's last plane they re-read it); 2: unconditionally through a buffer window that closes past the last
+                                 // plane (the loads then move nothing).  1 and 2 leave no vector-memory instruction of the loop under a
+                                 // branch, so the compiler's s_waitcnt vmcnt(N) counts are exact
+    std::vector<std::string> cc_opts;   // --cc-opt <flag> (repeatable): extra hipcc flags for this kernel (e.g. -fno-slp-vectorize); part of the
+                                 // kernel's identity: printed in the banner's build line and applied by drs_kernel_build
+    std::string store_mask = "branch";  // branch: plain global stores under per-lane guards (default: measured faster);
+                                 // buffer: outputs leave through buffer_store with the lane's offset set out of range where the
+                                 // lane must not store (dropped by the hardware's range check, no exec mask, no branch)
+    std::string schedule = "scatter";  // scatter: every partial sum carried in VGPRs; window: rotating register windows, nothing carried;
+                                 // reuse: `Range` planes in register windows + the rest carried (the reference's split for --dist)
+    bool schedule_set = false;   // --schedule given (else an explicit --dist selects "reuse")
 };
 
 struct Tap {

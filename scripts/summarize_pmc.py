@@ -1,14 +1,21 @@
 #!/usr/bin/env python3
-"""summarize_pmc.py <tag> <command> -- condense the rocprofv3 passes of scripts/profile_bench.sh for the dr_ kernel:
-average duration from the --stats pass, per-launch averages of every counter, HBM traffic per launch =
+"""summarize_pmc.py <tag> <command> [steps] -- condense the rocprofv3 passes of scripts/profile_bench.sh for the dr_ kernel.
+
+Durations come from the per-dispatch kernel trace of the --stats pass with the WARM-UP DISPATCHES EXCLUDED: only the last
+steps * launches_per_step dispatches (bench.py's timed region) are averaged, so `timed_avg_ns` is comparable with the same
+run's HIP-event figure (`bench_avg_launch_ms_same_run_hip_events`); min / median / max of those dispatches are recorded too,
+next to the all-dispatch averages rocprofv3's own stats file reports (which mix in the cold warm-up launches).
+Counters: per-launch averages over the timed dispatches of every --pmc pass found; HBM traffic per launch =
 FETCH_SIZE x 1 KiB x 2 (gfx950 correction, MI355X_MICROARCH.md) + WRITE_SIZE x 1 KiB.  Pure CSV parsing (no GPU)."""
 import csv
 import glob
 import json
 import os
+import statistics
 import sys
 
 tag, command = sys.argv[1], sys.argv[2]
+steps = int(sys.argv[3]) if len(sys.argv) > 3 else None
 root = os.path.join("gpurun_out", "prof_" + tag)
 csv.field_size_limit(1 << 30)
 
@@ -23,40 +30,61 @@ bench = None
 for line in open(os.path.join(root, "trace.log"), errors="replace"):
     if line.startswith("{") and '"metric"' in line:
         bench = json.loads(line)
+timed = None
 if bench:
     out["generator_options"] = bench["config"]["generator_options"]
     out["workload"] = bench["config"]["workload"]
     out["bench_avg_launch_ms_same_run_hip_events"] = bench["roofline"]["avg_launch_ms"]
     out["algorithmic_bytes_per_launch"] = bench["roofline"]["algorithmic_bytes_per_launch"]
+    out["device"] = bench.get("device")
+    timed = bench["steps"] * bench["config"]["launches_per_step"]
+elif steps:
+    timed = steps * 2
 stats = one("trace/*/*kernel_stats.csv")
-rows = list(csv.DictReader(open(stats)))
-with open(os.path.join("gpurun_out", tag + "_kernel_stats.csv"), "w") as f:
-    w = csv.DictWriter(f, fieldnames=list(rows[0].keys()))
-    w.writeheader()
+if stats:
+    rows = list(csv.DictReader(open(stats)))
+    with open(os.path.join("gpurun_out", tag + "_kernel_stats.csv"), "w") as f:
+        w = csv.DictWriter(f, fieldnames=list(rows[0].keys()))
+        w.writeheader()
+        for r in rows:
+            r = dict(r)
+            r["Name"] = r["Name"][:80]
+            w.writerow(r)
     for r in rows:
-        r = dict(r)
-        r["Name"] = r["Name"][:80]
-        w.writerow(r)
-for r in rows:
-    if r["Name"].startswith("dr_"):
-        out["kernel"] = r["Name"]
-        out["calls"] = int(r["Calls"])
-        out["avg_ns"] = float(r["AverageNs"])
-        out["min_ns"] = float(r["MinNs"])
-        out["max_ns"] = float(r["MaxNs"])
-for sub in ("fetch", "write", "tcc", "sq"):
-    f = one(sub + "/*/*counter_collection.csv")
-    if not f:
-        continue
+        if r["Name"].startswith("dr_"):
+            out["kernel"] = r["Name"]
+            out["all_dispatches"] = {"calls": int(r["Calls"]), "avg_ns": float(r["AverageNs"]), "min_ns": float(r["MinNs"]), "max_ns": float(r["MaxNs"]),
+                                     "note": "rocprofv3 --stats over every dispatch, cold warm-up launches included"}
+trace = one("trace/*/*kernel_trace.csv")
+if trace:
+    d = [(int(r["Start_Timestamp"]), int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) for r in csv.DictReader(open(trace)) if r["Kernel_Name"].startswith("dr_")]
+    d.sort()
+    dur = [x[1] for x in d]
+    if timed and len(dur) >= timed:
+        dur = dur[-timed:]
+    if dur:
+        out["timed_dispatches"] = len(dur)
+        out["timed_avg_ns"] = sum(dur) / len(dur)
+        out["timed_min_ns"] = min(dur)
+        out["timed_median_ns"] = statistics.median(dur)
+        out["timed_max_ns"] = max(dur)
+        out["avg_ns"] = out["timed_avg_ns"]
+        if bench:
+            out["timed_avg_over_hip_events"] = out["timed_avg_ns"] * 1e-6 / out["bench_avg_launch_ms_same_run_hip_events"]
+for f in sorted(glob.glob(os.path.join(root, "*/*/*counter_collection.csv"))):
     acc = {}
     for r in csv.DictReader(open(f)):
         if not r["Kernel_Name"].startswith("dr_"):
             continue
-        acc.setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
+        acc.setdefault(r["Counter_Name"], []).append((int(r["Dispatch_Id"]), float(r["Counter_Value"])))
         out.setdefault("vgpr", r["VGPR_Count"]); out.setdefault("lds", r["LDS_Block_Size"])
         out.setdefault("grid", r["Grid_Size"]); out.setdefault("wg", r["Workgroup_Size"])
     for k, v in acc.items():
-        out[k] = sum(v) / len(v)
+        v.sort()
+        vals = [x[1] for x in v]
+        if timed and len(vals) >= timed:
+            vals = vals[-timed:]
+        out[k] = sum(vals) / len(vals)
 if "FETCH_SIZE" in out and "WRITE_SIZE" in out:
     out["fetch_bytes_corrected_x2"] = out["FETCH_SIZE"] * 1024 * 2
     out["write_bytes"] = out["WRITE_SIZE"] * 1024
@@ -65,8 +93,14 @@ if "FETCH_SIZE" in out and "WRITE_SIZE" in out:
         out["traffic_over_algorithmic"] = out["traffic_bytes_per_launch"] / out["algorithmic_bytes_per_launch"]
 if "TCC_HIT_sum" in out:
     out["l2_hit_rate"] = out["TCC_HIT_sum"] / (out["TCC_HIT_sum"] + out["TCC_MISS_sum"])
-if "SQ_WAIT_ANY" in out:
+if "SQ_WAIT_ANY" in out and "SQ_WAVE_CYCLES" in out:
     out["wait_any_frac"] = out["SQ_WAIT_ANY"] / out["SQ_WAVE_CYCLES"]
+if "SQ_LDS_BANK_CONFLICT" in out:
     out["lds_conflict_frac"] = out["SQ_LDS_BANK_CONFLICT"] / max(out["SQ_LDS_IDX_ACTIVE"], 1)
+if "TCC_EA0_RDREQ_LEVEL_sum" in out and out.get("TCC_EA0_RDREQ_sum"):
+    out["ea_read_latency_cycles"] = out["TCC_EA0_RDREQ_LEVEL_sum"] / out["TCC_EA0_RDREQ_sum"]
+    out["ea_write_latency_cycles"] = out["TCC_EA0_WRREQ_LEVEL_sum"] / max(out["TCC_EA0_WRREQ_sum"], 1)
 json.dump(out, open(os.path.join("gpurun_out", tag + "_counters.json"), "w"), indent=1)
-print(json.dumps({k: out[k] for k in out if k in ("kernel", "avg_ns", "bench_avg_launch_ms_same_run_hip_events", "traffic_over_algorithmic", "l2_hit_rate", "wait_any_frac", "vgpr")}))
+keys = ("kernel", "timed_avg_ns", "timed_min_ns", "timed_median_ns", "bench_avg_launch_ms_same_run_hip_events", "timed_avg_over_hip_events", "traffic_over_algorithmic", "l2_hit_rate",
+        "wait_any_frac", "lds_conflict_frac", "ea_read_latency_cycles", "ea_write_latency_cycles", "vgpr")
+print(json.dumps({k: out[k] for k in keys if k in out}))

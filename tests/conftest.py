@@ -200,3 +200,11 @@ def pytest_sessionstart(session):
         for r in range(world):
             for every in (1, 2):
                 sw.prebuild(SlabPlan(cut, spec.halo, world, r, every))
+    # ... and of test_c4_slab_views_at_full_size: what bench.py --gpus 2/4/8 launches
+    import bench
+    from gpu_cases import C4_SLAB_WORLDS
+    for world in C4_SLAB_WORLDS:
+        sw = HipSweep(bench.WORKLOADS["c4"]["stc"], bench.slab_options("c4", world), SLAB_CACHE)
+        for r in range(world):
+            for every in (1, 2):
+                sw.prebuild(SlabPlan(1024, 2, world, r, every))

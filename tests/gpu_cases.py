@@ -62,23 +62,37 @@ _add("2d25_fp64_t2_tile", 2, "t2_box25", "--dtype", "fp64", "--step", "2", "--te
 
 SMOKE = ("smoke3", 3, stc("smoke3"), ["--3d", "--dtype", "fp32"])
 
-# BASELINE.json configs at full size: (id, ndim, stc, options)
+# BASELINE.json configs at full size: (id, ndim, stc, options).  Default-option kernels first, then EVERY kernel bench.py can
+# time (bench.kernels(): headline, step-1 and temporal kernels of every workload, the fp64 workloads included), so that no
+# number bench.py prints comes from a kernel without a full-size parity case.
 FULL = [
     ("C2_2d5pt_8192_fp32_tile", 2, os.path.join(CFG, "c2_2d5pt_star_8192.stc"), ["--dtype", "fp32"]),
     ("C2_2d5pt_8192_fp32_stream", 2, os.path.join(CFG, "c2_2d5pt_star_8192.stc"), ["--dtype", "fp32", "--streaming"]),
     ("C3_3d7pt_512_fp32", 3, os.path.join(CFG, "c3_3d7pt_star_512.stc"), ["--3d", "--dtype", "fp32"]),
     ("C3_3d7pt_512_fp32_step2", 3, os.path.join(CFG, "c3_3d7pt_star_512.stc"), ["--3d", "--dtype", "fp32", "--step", "2"]),
     ("C4_3d7pt_1024_fp32", 3, os.path.join(CFG, "c4_3d7pt_star_1024.stc"), ["--3d", "--dtype", "fp32"]),
-    ("C4_3d7pt_1024_fp32_temporal2", 3, os.path.join(CFG, "c4_3d7pt_star_1024.stc"),
-     ["--3d", "--dtype", "fp32", "--step", "2", "--temporal", "1", "--prefetch", "--bx", "66", "--by", "15", "--block-merge-x", "4",
-      "--block-merge-y", "2", "--sn", "32", "--xcd-remap", "0"]),
-    ("C4_3d7pt_1024_fp32_fused2_bench_headline", 3, os.path.join(CFG, "c4_3d7pt_star_1024.stc"),
-     ["--3d", "--dtype", "fp32", "--step", "2", "--prefetch", "--prefetch-depth", "3", "--bx", "32", "--by", "16", "--block-merge-x", "4", "--block-merge-y", "2", "--sn", "32",
-      "--xcd-remap", "2"]),
-    ("C4_3d7pt_1024_fp32_step1_tuned", 3, os.path.join(CFG, "c4_3d7pt_star_1024.stc"),
-     ["--3d", "--dtype", "fp32", "--prefetch", "--bx", "256", "--by", "2", "--block-merge-x", "4", "--block-merge-y", "4", "--sn", "4", "--xcd-remap", "2"]),
     ("C5_2d25pt_16384_fp64", 2, os.path.join(CFG, "c5_2d25pt_box_16384.stc"), ["--dtype", "fp64"]),
 ]
+
+
+def _bench_kernels():
+    import sys
+    if ROOT not in sys.path:
+        sys.path.insert(0, ROOT)
+    import bench
+    seen = {(c[2], tuple(c[3])) for c in FULL}
+    for kid, w, opts in bench.kernels():
+        wl = bench.WORKLOADS[w]
+        if (wl["stc"], tuple(opts)) not in seen:
+            seen.add((wl["stc"], tuple(opts)))
+            FULL.append((kid, wl["ndim"], wl["stc"], list(opts)))
+
+
+_bench_kernels()
+
+# BASELINE config C4 AS WRITTEN ("z-slab decomposition across 8 x MI355X"): the slab-view and pair-launch kernels that
+# bench.py --gpus 2/4/8 launches, at 1024^3, every rank in turn on one GPU (tests/test_gpu_parity.py::test_c4_slab_views_at_full_size)
+C4_SLAB_WORLDS = (2, 4, 8)
 
 
 # BASELINE config C1: 2d5pt_star 4096^2 fp32, 100 iterations (the reference-CPU-path config): HIP vs oracle at full size

@@ -1,0 +1,81 @@
+"""bench.py --gpus N as a plain command (no torch.distributed.run): it must start N rank processes itself, BEFORE anything
+in the parent imports torch or touches HIP (a launcher hop is only legal before any GPU call), relay rank 0's JSON line and
+propagate failures.  The rank command is stubbed through DRS_BENCH_CHILD, so no GPU is needed."""
+import json
+import os
+import subprocess
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+STUB = r'''
+import json, os, sys, time
+out = os.environ["STUB_OUT"]
+tag = "prebuild" if "--prebuild-only" in sys.argv else "rank_" + os.environ.get("RANK", "none")
+keys = ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "DRS_NO_COMPILE", "HSA_ENABLE_IPC_MODE_LEGACY")
+json.dump({"argv": sys.argv[1:], "env": {k: os.environ.get(k) for k in keys}, "pid": os.getpid()}, open(os.path.join(out, tag + ".json"), "w"))
+if tag == "prebuild":
+    sys.exit(0)
+fail = os.environ.get("STUB_FAIL_RANK")
+if fail is not None:
+    if os.environ["RANK"] == fail:
+        sys.exit(3)
+    time.sleep(60)          # the other ranks would wait in RCCL for ever: the parent has to end them
+if os.environ["RANK"] == "0":
+    print(json.dumps({"metric": "stub", "value": 1.0, "n_gpus": int(os.environ["WORLD_SIZE"])}))
+'''
+
+PARENT = r'''
+import sys
+sys.path.insert(0, %r)
+import bench
+code = 0
+try:
+    bench.main(%r)
+except SystemExit as e:
+    code = e.code or 0
+assert "torch" not in sys.modules, "the parent imported torch"
+assert "drstencil_amd" not in sys.modules, "the parent loaded the native library"
+sys.exit(code)
+'''
+
+
+def _run(tmp_path, argv, extra_env=None, timeout=60):
+    stub = tmp_path / "stub.py"
+    stub.write_text(STUB)
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "DRS_REHEARSE")}
+    env.update(DRS_BENCH_CHILD=json.dumps([sys.executable, str(stub)]), STUB_OUT=str(tmp_path))
+    env.update(extra_env or {})
+    return subprocess.run([sys.executable, "-c", PARENT % (ROOT, argv)], env=env, capture_output=True, text=True, timeout=timeout)
+
+
+def test_gpus_n_starts_n_ranks_with_the_rendezvous_environment(tmp_path):
+    r = _run(tmp_path, ["--gpus", "4", "--steps", "3", "--warmup", "1"])
+    assert r.returncode == 0, r.stdout + r.stderr
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line["metric"] == "stub" and line["n_gpus"] == 4                 # rank 0's line, relayed
+    pre = json.load(open(tmp_path / "prebuild.json"))
+    assert pre["argv"] == ["--gpus", "4", "--steps", "3", "--warmup", "1", "--prebuild-only"] and pre["env"]["RANK"] is None
+    ranks = [json.load(open(tmp_path / ("rank_%d.json" % i))) for i in range(4)]
+    ports = {x["env"]["MASTER_PORT"] for x in ranks}
+    assert len(ports) == 1 and int(ports.pop()) > 0
+    assert len({x["pid"] for x in ranks}) == 4
+    for i, x in enumerate(ranks):
+        e = x["env"]
+        assert x["argv"] == ["--gpus", "4", "--steps", "3", "--warmup", "1"]
+        assert (e["RANK"], e["LOCAL_RANK"], e["WORLD_SIZE"], e["LOCAL_WORLD_SIZE"]) == (str(i), str(i), "4", "4")
+        assert e["MASTER_ADDR"] == "127.0.0.1" and e["DRS_NO_COMPILE"] == "1" and e["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+
+
+def test_a_failed_rank_ends_the_others_and_the_exit_code_is_propagated(tmp_path):
+    t0 = time.time()
+    r = _run(tmp_path, ["--gpus", "3"], {"STUB_FAIL_RANK": "1"})
+    assert r.returncode == 3, (r.returncode, r.stdout, r.stderr)
+    assert time.time() - t0 < 30, "the surviving ranks were not terminated"
+
+
+def test_world_size_mismatch_is_refused_before_the_gpu_is_touched(tmp_path):
+    # as one rank of a launcher (WORLD_SIZE set) with a --gpus that does not match: an error, not an assert after HIP init
+    r = _run(tmp_path, ["--gpus", "4"], {"WORLD_SIZE": "2", "RANK": "0"})
+    assert r.returncode != 0 and "WORLD_SIZE=2" in (r.stdout + r.stderr)

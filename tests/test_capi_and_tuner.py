@@ -105,12 +105,74 @@ def test_kernel_resources_and_scratch_refusal(monkeypatch):
     assert k2.resources["scratch_bytes_per_lane"] > 0
 
 
-def test_bench_headline_kernel_is_a_full_size_parity_case():
+def test_cache_key_keeps_the_whole_hash_for_long_names(tmp_path):
+    """A .stc whose base name is longer than the readable part of the cache key: two option sets (or dtypes) must still
+    get two different cached kernels (the round-1 key was a 64-byte buffer, so a long name truncated the hash away and
+    an fp32 plugin was handed back for an fp64 request)."""
+    import shutil
+    long_stc = str(tmp_path / ("a_very_long_stencil_specification_name_that_goes_on_and_on_for_seventy_chars" + ".stc"))
+    shutil.copy(os.path.join(ROOT, "tests", "stc", "t2_star.stc"), long_stc)
+    cache = str(tmp_path / "cache")
+    k32 = drs.Kernel(["--dtype", "fp32", long_stc], cache_dir=cache)
+    k64 = drs.Kernel(["--dtype", "fp64", "--bx", "32", long_stc], cache_dir=cache)
+    assert k32.path != k64.path
+    assert k32.info["dtype"] == "fp32" and k64.info["dtype"] == "fp64" and k64.info["threads"] != k32.info["threads"]
+    for k in (k32, k64):
+        stem = os.path.basename(k.path)[:-3]
+        assert re.fullmatch(r"[A-Za-z0-9_]{1,40}_[0-9a-f]{16}", stem), stem
+
+
+def test_unverified_and_uncompilable_kernels_are_refused(monkeypatch, tmp_path):
+    """Fail closed: (1) a compiler whose resource report cannot be read (here: a DRS_HIPCC wrapper that drops stderr) gives
+    a kernel that was never checked for AGPR spilling / scratch, so it is not loaded unless DRS_ALLOW_UNVERIFIED=1;
+    (2) DRS_NO_COMPILE=1 turns a cache miss into an error instead of a hipcc child process; (3) --pair-launch kernels
+    report the maximum over dr_ and dr2_; (4) --debug-drop-barrier kernels (wrong results by design) need DRS_EXPERIMENTS=1."""
+    stc = os.path.join(ROOT, "tests", "stc", "t2_star.stc")
+    wrapper = tmp_path / "quiet_hipcc.sh"
+    wrapper.write_text("#!/bin/sh\nexec /opt/rocm/bin/hipcc \"$@\" 2>/dev/null\n")
+    wrapper.chmod(0o755)
+    monkeypatch.setenv("DRS_HIPCC", str(wrapper))
+    monkeypatch.delenv("DRS_ALLOW_UNVERIFIED", raising=False)
+    with pytest.raises(drs.KernelBuildError) as e:
+        drs.Kernel(["--dtype", "fp32", stc], cache_dir=str(tmp_path / "c1"))
+    assert "no compiler resource report" in str(e.value) and "DRS_ALLOW_UNVERIFIED" in str(e.value)
+    monkeypatch.setenv("DRS_ALLOW_UNVERIFIED", "1")
+    k = drs.Kernel(["--dtype", "fp32", stc], cache_dir=str(tmp_path / "c1"))
+    assert k.resources["verified"] == 0 and k.resources["vgprs"] == -1
+    monkeypatch.delenv("DRS_ALLOW_UNVERIFIED")
+    monkeypatch.delenv("DRS_HIPCC")
+    # (2)
+    monkeypatch.setenv("DRS_NO_COMPILE", "1")
+    with pytest.raises(drs.KernelBuildError) as e:
+        drs.Kernel(["--dtype", "fp32", stc], cache_dir=str(tmp_path / "c2"))
+    assert "not in the cache" in str(e.value) and "DRS_NO_COMPILE" in str(e.value)
+    monkeypatch.delenv("DRS_NO_COMPILE")
+    # (3)
+    t3 = os.path.join(ROOT, "tests", "stc", "t3_star.stc")
+    kp = drs.Kernel(["--3d", "--dtype", "fp32", "--pair-launch", "1", t3], cache_dir=str(tmp_path / "c3"))
+    assert kp.resources["kernels_reported"] == "dr_+dr2_" and kp.resources["verified"] == 1 and kp.resources["vgprs"] > 0
+    # (4)
+    monkeypatch.delenv("DRS_EXPERIMENTS", raising=False)
+    with pytest.raises(drs.KernelBuildError) as e:
+        drs.Kernel(["--3d", "--dtype", "fp32", "--debug-drop-barrier", "2", t3], cache_dir=str(tmp_path / "c3"))
+    assert "DRS_EXPERIMENTS" in str(e.value)
+
+
+def test_every_bench_kernel_is_a_full_size_parity_case():
+    """No number bench.py prints may come from a kernel without a full-size parity case: every (workload, options) pair of
+    bench.kernels() -- headline, step-1 and temporal kernels, fp64 workloads included -- is in gpu_cases.FULL, and the
+    slab-view kernels of the N > 1 branch are covered by test_c4_slab_views_at_full_size for the same world sizes
+    __graft_entry__.build() prebuilds."""
     import bench
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import gpu_cases
-    head = [c for c in gpu_cases.FULL if "bench_headline" in c[0]]
-    assert head and head[0][3] == bench.TUNED["c4"] and head[0][2] == bench.WORKLOADS["c4"]["stc"]
+    full = {(c[2], tuple(c[3])) for c in gpu_cases.FULL}
+    ks = bench.kernels()
+    assert len(ks) >= 11 and {w for _, w, _ in ks} == set(bench.WORKLOADS)
+    for kid, w, opts in ks:
+        assert (bench.WORKLOADS[w]["stc"], tuple(opts)) in full, kid
+    assert [o + [bench.WORKLOADS[w]["stc"]] for _, w, o in ks] == bench.kernel_arg_sets()
+    assert gpu_cases.C4_SLAB_WORLDS == (2, 4, 8)
 
 
 def test_tuner_space_and_naming():

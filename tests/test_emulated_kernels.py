@@ -62,10 +62,44 @@ VARIANTS = [
     ("3d_step2_prefetch_depth2", 3, "STAR3", (23, 21, 300), ["--3d", "--dtype", "fp32", "--sn", "7", "--step", "2", "--prefetch", "--prefetch-depth", "2"]),
     ("3d_step1_prefetch_depth3", 3, "STAR3", (19, 23, 270), ["--3d", "--dtype", "fp64", "--sn", "5", "--prefetch", "--prefetch-depth", "3", "--xrim", "lds"]),
     ("2d_stream_prefetch_depth2", 2, "STAR2", (1, 75, 530), ["--dtype", "fp32", "--streaming", "--prefetch", "--prefetch-depth", "2", "--sn", "3"]),
+    # memory-pipeline variants (round 2): guarded loads / stores (round-1 form), re-read tail loads, window loads that close past the
+    # block's last plane, explicit drains; ragged grids so that out-of-grid lanes, partial vectors and short blocks all occur
+    ("3d_r1_memory_path", 3, "STAR3", (19, 23, 262), ["--3d", "--dtype", "fp32", "--sn", "7", "--step", "2", "--prefetch", "--uniform-loads", "0", "--store-mask", "branch"]),
+    ("3d_window_loads_depth2", 3, "STAR3", (19, 23, 262), ["--3d", "--dtype", "fp32", "--sn", "7", "--step", "2", "--prefetch", "--prefetch-depth", "2", "--uniform-loads", "2", "--drain", "1"]),
+    ("3d_window_loads_oddN", 3, "STAR3", (12, 17, 263), ["--3d", "--dtype", "fp64", "--sn", "3", "--prefetch", "--prefetch-depth", "3", "--uniform-loads", "2", "--drain", "2"]),
+    ("3d_window_loads_short_blocks", 3, "STAR3", (9, 11, 140), ["--3d", "--dtype", "fp32", "--sn", "1", "--prefetch", "--prefetch-depth", "3", "--uniform-loads", "2"]),
+    ("2d_stream_window_loads", 2, "BOX25", (1, 61, 268), ["--dtype", "fp32", "--streaming", "--sn", "9", "--prefetch", "--uniform-loads", "2", "--store-mask", "branch"]),
+    ("2d_tile_branch_stores", 2, "BOX9", (1, 41, 70), ["--dtype", "fp64", "--store-mask", "branch"]),
+    ("3d_buffer_stores_uniform_loads", 3, "STAR3", (19, 23, 262), ["--3d", "--dtype", "fp32", "--sn", "7", "--step", "2", "--prefetch", "--uniform-loads", "1", "--store-mask", "buffer"]),
+    ("2d_tile_buffer_stores", 2, "BOX9", (1, 41, 70), ["--dtype", "fp64", "--store-mask", "buffer"]),
+]
+
+# --dist / --merge-forward as real knobs: an explicit --dist selects --schedule reuse -- `Range` source planes in
+# register windows, partial sums carried over the rest -- over the reference's legal range (step-1)*order <= dist <= step*order
+# (benchmarks/3d7pt_star/tuning.py:20), --merge-forward deciding whether a retained plane's neighbours are carried or re-read.
+# Every one of them must equal the oracle bit for bit, like every other schedule.
+REUSE = [
+    ("3d_s1_dist1", 3, "STAR3", (19, 23, 262), ["--3d", "--dtype", "fp32", "--sn", "7", "--dist", "1"]),
+    ("3d_s1_dist1_prefetch_lds", 3, "STAR3", (12, 17, 263), ["--3d", "--dtype", "fp64", "--sn", "3", "--dist", "1", "--prefetch", "--xrim", "lds"]),
+    ("3d_s2_dist1", 3, "STAR3", (19, 23, 262), ["--3d", "--dtype", "fp32", "--sn", "7", "--step", "2", "--dist", "1", "--prefetch"]),
+    ("3d_s2_dist2", 3, "STAR3", (19, 23, 262), ["--3d", "--dtype", "fp32", "--sn", "7", "--step", "2", "--dist", "2", "--prefetch"]),
+    ("3d_s2_dist1_mf0", 3, "STAR3", (19, 23, 262), ["--3d", "--dtype", "fp64", "--sn", "5", "--step", "2", "--dist", "1", "--merge-forward", "0"]),
+    ("3d_s2_dist2_mf2_lds", 3, "STAR3", (17, 21, 300), ["--3d", "--dtype", "fp32", "--sn", "6", "--step", "2", "--dist", "2", "--merge-forward", "2", "--xrim", "lds", "--prefetch", "--prefetch-depth", "2"]),
+    ("3d_s2_dist2_mf100", 3, "STAR3", (17, 21, 300), ["--3d", "--dtype", "fp32", "--sn", "1", "--step", "2", "--dist", "2", "--merge-forward", "100"]),
+    ("3d_s3_dist2", 3, "STAR3", (23, 21, 140), ["--3d", "--dtype", "fp64", "--sn", "4", "--step", "3", "--dist", "2", "--bx", "16", "--by", "4", "--block-merge-x", "2", "--block-merge-y", "2"]),
+    ("3d_s3_dist3", 3, "STAR3", (23, 21, 140), ["--3d", "--dtype", "fp64", "--sn", "9", "--step", "3", "--dist", "3", "--bx", "16", "--by", "4", "--block-merge-x", "2", "--block-merge-y", "2", "--prefetch"]),
+    ("3d_cross_s1_dist2", 3, "CROSS3", (14, 19, 136), ["--3d", "--dtype", "fp32", "--dist", "2", "--sn", "4"]),
+    ("3d_cross_s2_dist4_cyclicy", 3, "CROSS3", (17, 29, 140), ["--3d", "--dtype", "fp64", "--step", "2", "--dist", "4", "--sn", "5", "--cyclic-merge-y", "2", "--by", "4", "--bx", "32"]),
+    ("2d_stream_s2_dist1", 2, "STAR2", (1, 75, 530), ["--dtype", "fp32", "--streaming", "--step", "2", "--dist", "1", "--sn", "16", "--prefetch"]),
+    ("2d_stream_box25_dist2_mf0", 2, "BOX25", (1, 61, 268), ["--dtype", "fp64", "--streaming", "--dist", "2", "--merge-forward", "0", "--sn", "9"]),
+    ("2d_stream_box25_s2_dist3", 2, "BOX25", (1, 61, 268), ["--dtype", "fp32", "--streaming", "--step", "2", "--dist", "3", "--sn", "9", "--prefetch"]),
+    ("2d_tile_dist_is_a_noop", 2, "BOX25", (1, 61, 268), ["--dtype", "fp32", "--dist", "2"]),
+    ("3d_window_schedule", 3, "STAR3", (19, 23, 262), ["--3d", "--dtype", "fp32", "--sn", "7", "--step", "2", "--schedule", "window", "--prefetch"]),
+    ("3d_window_schedule_eager", 3, "STAR3", (19, 23, 262), ["--3d", "--dtype", "fp64", "--sn", "3", "--schedule", "window", "--lazy-rims", "0"]),
 ]
 
 
-@pytest.mark.parametrize("vid,ndim,pts,dims,opts", VARIANTS, ids=[v[0] for v in VARIANTS])
+@pytest.mark.parametrize("vid,ndim,pts,dims,opts", VARIANTS + REUSE, ids=[v[0] for v in VARIANTS + REUSE])
 def test_emulated_variants_bit_exact(vid, ndim, pts, dims, opts, tmp_path):
     mg = _mg()
     stc = str(tmp_path / "v.stc")
@@ -99,6 +133,7 @@ EDGE = [
     ("2d_temporal2_tile_small", 2, "BOX9", (1, 7, 9), ["--dtype", "fp64", "--step", "2", "--temporal", "1"]),
     ("2d_oddN_box25_stream", 2, "BOX25", (1, 23, 31), ["--dtype", "fp64", "--streaming", "--sn", "4", "--xrim", "lds"]),
     ("3d_temporal2_prefetch_depth2", 3, "STAR3", (17, 21, 300), ["--3d", "--dtype", "fp64", "--sn", "6", "--step", "2", "--temporal", "1", "--prefetch", "--prefetch-depth", "2", "--by", "8", "--block-merge-y", "2"]),
+    ("3d_temporal2_window_loads", 3, "STAR3", (17, 21, 300), ["--3d", "--dtype", "fp64", "--sn", "6", "--step", "2", "--temporal", "1", "--prefetch", "--prefetch-depth", "2", "--by", "8", "--block-merge-y", "2", "--uniform-loads", "2", "--drain", "1"]),
 ]
 
 

@@ -407,6 +407,60 @@ def test_slab_decomposition_on_one_gpu(torch_cuda, cid, world, stencil, ndim, op
 
 
 @pytest.mark.parametrize("every", [1, 2], ids=["exchange_every_launch", "exchange_every_pair"])
+@pytest.mark.parametrize("world", [2, 4, 8])
+def test_c4_slab_views_at_full_size(torch_cuda, world, every):
+    """BASELINE config C4 as written (3d7pt_star 1024^3 fp32, z slabs across up to 8 GPUs): exactly what
+    `bench.py --gpus <world>` launches -- bench.slab_options("c4", world), the slab-view kernels for this world's view
+    lengths, the --pair-launch boundary kernel of the middle ranks, both exchange modes -- with every rank run in turn on
+    this one GPU (SlabRun + HipSweep, in-process exchange), against the single-domain bench headline kernel, bit for bit.
+    (The headline kernel itself is tied to the gold kernel and the oracle by test_full_size_properties.)"""
+    import bench
+    import drstencil_amd as drs
+    from drstencil_amd.multigpu import HipSweep, SlabRun
+    torch = torch_cuda
+    wl = bench.WORKLOADS["c4"]
+    stc = wl["stc"]
+    opts = bench.slab_options("c4", world)
+    full = drs.Kernel(bench.TUNED["c4"] + [stc])
+    step = _step(opts)
+    i = full.info
+    L, M, N, H = i["L"], i["M"], i["N"], i["halo"]
+    assert (L, M, N) == (1024, 1024, 1024) and step == 2 and H == 2
+    dev = torch.device("cuda", 0)
+    g = torch.Generator(device="cuda").manual_seed(77)
+    A0 = torch.rand((L, M, N), dtype=torch.float32, device=dev, generator=g)
+    A_ref = A0.clone(); B_ref = torch.zeros_like(A0)
+    n_ref = full.run(A_ref.data_ptr(), B_ref.data_ptr())
+    torch.cuda.synchronize()
+    hub = _Hub()
+    sweep = HipSweep(stc, opts, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "drstencil_amd", "_kcache"))
+    runs = [SlabRun(torch, _FakeDist(hub, r), (L, M, N), H, step, i["iterations"], r, world, sweep, dev, torch.float32, every=every) for r in range(world)]
+    used_pair = False
+    for r in runs:
+        r.load_global(lambda lo, hi: A0[lo:hi])
+        used_pair = used_pair or bool(r.plan.pair_view())
+    assert used_pair == (world > 2)                        # middle ranks send both boundary views in one dr2_ launch
+    t, n = 0, 0
+    while t < i["iterations"]:
+        for src, dst in (("A", "B"), ("B", "A")):
+            for r in runs:
+                if every == 2 and src == "A":
+                    r.launch_local(r.A, r.B)
+                else:
+                    r.launch(getattr(r, src), getattr(r, dst))
+            torch.cuda.synchronize()
+            hub.deliver()
+            assert not hub.pending
+            n += 1
+        t += 2 * step
+    assert n == n_ref
+    for r in runs:
+        p = r.plan
+        assert torch.equal(r.owned(r.A), A_ref[p.z0:p.z1]), "rank %d of %d: A" % (r.rank, world)
+        assert torch.equal(r.owned(r.B), B_ref[p.z0:p.z1]), "rank %d of %d: B" % (r.rank, world)
+
+
+@pytest.mark.parametrize("every", [1, 2], ids=["exchange_every_launch", "exchange_every_pair"])
 def test_rccl_exchange_choreography_on_one_gpu(torch_cuda, tmp_path, every):
     """The real RCCL transport under SlabRun's stream/event choreography, as far as one GPU can show it: this
     process is the only rank of an RCCL group and plays a middle rank whose two neighbours are itself (what it
