@@ -49,8 +49,11 @@ WORKLOADS = {
 # (profiles/r01_tune_c4_s2_exhaustive.txt) puts the 32x16-lane and 64x8-lane fused kernels and the 66x15-lane
 # temporal pipeline within a few per cent of each other; their order changes from device to device.
 TUNED = {
-    "c4": ["--3d", "--dtype", "fp32", "--step", "2", "--prefetch", "--prefetch-depth", "3", "--bx", "32", "--by", "16", "--block-merge-x", "4", "--block-merge-y", "2", "--sn", "32", "--xcd-remap", "2"],
-    "c3": ["--3d", "--dtype", "fp32", "--step", "2", "--prefetch", "--prefetch-depth", "3", "--bx", "32", "--by", "16", "--block-merge-x", "4", "--block-merge-y", "2", "--sn", "32", "--xcd-remap", "2"],
+    # round 2: + `-fno-slp-vectorize` for this kernel (the SLP vectoriser packs the 200 FMAs per lane and plane into v_pk_fma_f32,
+    # whose register-pair operands cost 935 v_mov per 24 planes; without it 202 VGPRs instead of 226 and 0.4-1 % less time in four
+    # interleaved comparisons, profiles/r02_exp_r2[a-d]*.log)
+    "c4": ["--3d", "--dtype", "fp32", "--step", "2", "--prefetch", "--prefetch-depth", "3", "--bx", "32", "--by", "16", "--block-merge-x", "4", "--block-merge-y", "2", "--sn", "32", "--xcd-remap", "2", "--cc-opt", "-fno-slp-vectorize"],
+    "c3": ["--3d", "--dtype", "fp32", "--step", "2", "--prefetch", "--prefetch-depth", "3", "--bx", "32", "--by", "16", "--block-merge-x", "4", "--block-merge-y", "2", "--sn", "32", "--xcd-remap", "2", "--cc-opt", "-fno-slp-vectorize"],
     # 2D one-shot LDS tiles (BASELINE C2 "no temporal blocking (baseline LDS tile)", C5 "wide-halo LDS staging"): best of the
     # exhaustive 2D searches, profiles/r01_tune_c2_exhaustive.txt / r01_tune_c5_exhaustive.txt (0.78 of the HBM peak each)
     "c2": ["--dtype", "fp32", "--bx", "128", "--by", "2", "--block-merge-x", "4", "--block-merge-y", "2", "--xcd-remap", "0"],

@@ -49,6 +49,7 @@ def lib():
     L.drs_kernel_build.restype = vp
     L.drs_kernel_build.argtypes = [ci, cpp, ctypes.c_char_p, ctypes.POINTER(vp)]
     L.drs_kernel_close.argtypes = [vp]
+    L.drs_kernel_unload.argtypes = [vp]
     L.drs_kernel_info.restype = ctypes.c_char_p
     L.drs_kernel_info.argtypes = [vp]
     L.drs_kernel_path.restype = ctypes.c_char_p
@@ -74,7 +75,7 @@ EXPORTS = [
     "drs_version", "drs_free", "drs_generate",
     "drs_spec_open", "drs_spec_close", "drs_spec_halo", "drs_spec_dist", "drs_spec_range", "drs_spec_npoints",
     "drs_spec_iterations", "drs_spec_launches", "drs_spec_dims", "drs_spec_point", "drs_spec_partition",
-    "drs_kernel_build", "drs_kernel_close", "drs_kernel_info", "drs_kernel_path", "drs_kernel_resources", "drs_kernel_launch", "drs_kernel_launch_pair",
+    "drs_kernel_build", "drs_kernel_close", "drs_kernel_unload", "drs_kernel_info", "drs_kernel_path", "drs_kernel_resources", "drs_kernel_launch", "drs_kernel_launch_pair",
     "drs_kernel_launch_gold", "drs_kernel_run", "drs_kernel_run_timed",
     "drs_fill_random_f64", "drs_fill_random_f32", "drs_check_error_f64", "drs_check_error_f32",
 ]
@@ -233,6 +234,13 @@ class Kernel:
                 self.h = None
         except Exception:   # interpreter shutdown
             pass
+
+    def unload(self):
+        """close() and unmap the plugin (device synchronised first): sweeps over thousands of kernels."""
+        if getattr(self, "h", None):
+            h, self.h = self.h, None
+            if lib().drs_kernel_unload(h) != 0:
+                raise RuntimeError("drs_kernel_unload failed")
 
     __del__ = close
 

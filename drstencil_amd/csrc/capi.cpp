@@ -341,6 +341,14 @@ void drs_kernel_close(drs_kernel *k) {
     // the code object stays registered with the HIP runtime; leave the library mapped
     delete k;
 }
+int drs_kernel_unload(drs_kernel *k) {
+    if (!k) return 0;
+    int rc = 0;
+    if (g_launched && hipDeviceSynchronize() != hipSuccess) rc = -1;     // nothing of this plugin is running any more
+    if (k->dl && dlclose(k->dl) != 0) rc = -1;
+    delete k;
+    return rc;
+}
 const char *drs_kernel_info(const drs_kernel *k) { return k->info(); }
 const char *drs_kernel_path(const drs_kernel *k) { return k->path.c_str(); }
 const char *drs_kernel_resources(const drs_kernel *k) { return k->resources.c_str(); }

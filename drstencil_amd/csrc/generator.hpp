@@ -199,6 +199,7 @@ inline GenResult generate(const std::vector<std::string> &args /* argv[1..] */) 
 
     res.plan = make_plan(st, o, kernel_base_name(stcfile));
     if (!res.plan.error.empty()) { res.messages += "Invalid configuration!\n"; res.exit_code = 255; return res; }
+    if (!res.plan.note.empty()) res.messages += "drstencil: note: " + res.plan.note + "\n";
     std::string cmdline;
     for (size_t i = 0; i + 1 < args.size(); i++) cmdline += (i ? " " : "") + args[i];
     HipEmitter em(res.plan, o);

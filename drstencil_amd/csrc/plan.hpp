@@ -136,6 +136,7 @@ struct KernelPlan {
     bool prefetch = false;
     int PD = 1;              // prefetch depth (planes in flight)
     std::string error;       // non-empty: invalid configuration
+    std::string note;        // non-empty: something the user asked for was not done (printed by the generator, kept in the banner)
 };
 
 inline int ceil_div(int a, int b) { return (a + b - 1) / b; }

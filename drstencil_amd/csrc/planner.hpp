@@ -140,6 +140,9 @@ inline KernelPlan make_plan(const Stencil &st, const GenOptions &o_in, const std
     if (temporal)
         for (auto &e : st.pts.v)
             if (std::fabs(coef_rounded(e.second) - e.second) > 1e-12 * std::fabs(e.second)) temporal = false;
+    if (o.temporal && st.step > 1 && !temporal)
+        p.note = "--temporal 1 ignored: rounding the fused coefficients to 6 digits is not a no-op for this stencil, so on-chip "
+                 "stages would not equal the reference's fused arithmetic; the fused single-pass kernel is emitted instead";
     p.stages = temporal ? st.step : 1;
     if (temporal) for (auto &e : st.base.v) p.taps.push_back(to_tap(e, true));
     else p.taps = p.gtaps;

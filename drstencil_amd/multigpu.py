@@ -135,7 +135,9 @@ def measure_exchange_every(torch, dist, dims, H, rank, world, sweep, device, dty
         torch.cuda.synchronize()
         return e0.elapsed_time(e1) / reps * 1e3
 
-    sweep_us = timed(lambda: sweep(src[a:b], dst[a:b], main.cuda_stream))
+    # a rank that owns exactly 2H planes has no interior view (SlabRun.launch skips it as well): nothing to time, and asking
+    # for a kernel without interior would raise here while the other ranks wait in all_reduce
+    sweep_us = timed(lambda: sweep(src[a:b], dst[a:b], main.cuda_stream)) if b - a > 2 * H else 0.0
     up = 0 if self_neighbour else rank - 1
     dn = 0 if self_neighbour else rank + 1
     has_up, has_dn = (p.has_up or self_neighbour), (p.has_dn or self_neighbour)

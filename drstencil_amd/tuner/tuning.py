@@ -10,14 +10,28 @@ sweep -> per-config generate/compile/measure -> append every improvement to dura
 rocprofv3 instead of Nsight Compute:
 
   space vector = (step, dist, (bx, by), sn, unroll, blockMergeX, mx, blockMergeY, my,
-                  mergeForward, prefetch, xrim, temporal, xcd, streaming)
+                  mergeForward, prefetch, xrim, temporal, xcd, streaming[, schedule])
+  * schedule (optional 16th element, default "scatter"): "reuse" = the reference's split for `dist` -- `Range` source planes
+    resident in register windows, partial sums carried over the rest -- swept over the reference's legal range
+    (step-1)*order <= dist <= step*order (benchmarks/3d7pt_star/tuning.py:20,110-112); "scatter" carries everything
   * bx in {16,32,64,128,256}: lanes along x; mx in {1,2,4} points per lane (16-byte
     accesses at mx=4 fp32 / 2 fp64); by*my rows per tile; sn planes per stream block
   * prefetch = planes of software prefetch in flight (0 off, True == 1; `p` / `p3` in the name)
   * LDS budget 160 KiB per CU (the reference caps at 32 KiB of A100 shared memory)
   * `duration` = average kernel duration in ns from HIP events over the reference's timed
     loop (10 warm-up launches first, codegen.hpp:575-584), i.e. what `ncu ... Duration` was
-    for the reference; `rocprof_metrics()` adds FETCH_SIZE/WRITE_SIZE for chosen configs.
+    for the reference.  Every new best is CHECKED against the emitted gold kernel before it is
+    recorded (the reference's tuner passes --check and never reads the result).
+  * `rocprof_metrics()` then takes the best configurations through the reference's own
+    per-configuration flow (tuning.py:132-137 -> compile_run.sh -> getGpuMetrics.py): drstencil
+    --check -o cu/<name>.hip, hipcc, the emitted program under rocprofv3 (trace, FETCH_SIZE and
+    WRITE_SIZE runs), one gpuMetrics.csv row each -- in clean worker processes, never in the
+    measuring process.
+  * registerFilter() drops configurations whose per-lane state cannot fit the register file at
+    their workgroup size BEFORE anything is compiled (the reference filters before compiling
+    too, tuning.py:13-37): the generator reports the registers its named state needs
+    (`reg_demand` in the kernel info), and a linear model fitted to the compiler's resource
+    reports (profiles/r02_reg_model.md) turns that into allocated registers.
 
 The config-name scheme (`fu2d1bx16y8sn8u4cmx1cmy1mf5[p]`) and the command-line mapping are
 the reference's, with suffixes for the additive options, so logs stay comparable.
@@ -42,22 +56,33 @@ ndim = 3
 elem_bytes = 4
 
 
+def _unpack(spaceVector):
+    """15-element vectors (round 1, the reference's layout + our suffix fields) mean --schedule scatter."""
+    v = tuple(spaceVector)
+    return v if len(v) == 16 else v + ("scatter",)
+
+
 def FilterParams(spaceVector):
-    step, dist, blockSize, sn, s_unroll, blockMergeX, mergeFactorX, blockMergeY, mergeFactorY, m_threshold, prefetch, xrim, temporal, xcd, streaming = spaceVector
+    step, dist, blockSize, sn, s_unroll, blockMergeX, mergeFactorX, blockMergeY, mergeFactorY, m_threshold, prefetch, xrim, temporal, xcd, streaming, schedule = _unpack(spaceVector)
     halo = step * order
     tx = mergeFactorX * blockSize[0]
     ty = 1 if streaming else mergeFactorY * blockSize[1]
     # LDS: 2 planes (3 for an odd number of on-chip stages) x (rows + halo pads) x (row + x halo)
     stage_halo = order if temporal else halo
     slots = 3 if (temporal and step % 2 == 1 and step > 1) else 2
+    if schedule == "reuse":
+        # retained planes whose neighbours are re-read late keep their LDS slots: at most one slot per resident plane + 1
+        slots = max(slots, 2 * halo + 3 - dist)
+    if prefetch and int(prefetch) > 1 and not temporal:
+        slots = max(slots, int(prefetch) + 1)      # deeper prefetch may rotate one LDS slot per register set
     ldsUsage = slots * (ty + 2 * stage_halo) * (tx + 8) * elem_bytes
     if temporal and step == 1:
         return False
-    # the scatter schedule keeps (Range-1) partial-sum planes + one window per stage in VGPRs
-    stages = step if temporal else 1
-    vgprEstimate = stages * (3 * mergeFactorX * mergeFactorY + 2 * (mergeFactorX + mergeFactorY)) * (1 if temporal or step == 1 else step * step)
-    if vgprEstimate > 200:
+    # (register demand is not estimated here: registerFilter() asks the generator, which knows the stencil's shape)
+    if schedule not in ("scatter", "reuse"):
         return False
+    if schedule == "reuse" and (temporal or (ndim == 2 and not streaming)):
+        return False              # on-chip stages always carry; the one-shot tile kernel has no streamed dimension
     if ldsUsage > maxLdsPerBlock:
         return False
     # dist too big or too small (reference rule; dist > halo is wrong in the reference)
@@ -89,7 +114,7 @@ def FilterParams(spaceVector):
 
 
 def cfgToCommandLine(spaceVector):
-    step, dist, blockSize, sn, s_unroll, blockMergeX, mergeFactorX, blockMergeY, mergeFactorY, m_threshold, prefetch, xrim, temporal, xcd, streaming = spaceVector
+    step, dist, blockSize, sn, s_unroll, blockMergeX, mergeFactorX, blockMergeY, mergeFactorY, m_threshold, prefetch, xrim, temporal, xcd, streaming, schedule = _unpack(spaceVector)
     cmd = " --bx {0} --by {1} --sn {2} --stream-unroll {3}".format(blockSize[0], blockSize[1], sn, s_unroll)
     cmd += " --step {0} --dist {1}".format(step, dist)
     if blockMergeX:
@@ -108,18 +133,20 @@ def cfgToCommandLine(spaceVector):
         cmd += " --temporal 1"
     if streaming:
         cmd += " --streaming"
+    if schedule == "scatter":
+        cmd += " --schedule scatter"     # --dist is always on the command line (reference scheme) and alone would select reuse
     return cmd
 
 
 def cfgToString(spaceVector):
-    step, dist, blockSize, sn, s_unroll, blockMergeX, mergeFactorX, blockMergeY, mergeFactorY, m_threshold, prefetch, xrim, temporal, xcd, streaming = spaceVector
+    step, dist, blockSize, sn, s_unroll, blockMergeX, mergeFactorX, blockMergeY, mergeFactorY, m_threshold, prefetch, xrim, temporal, xcd, streaming, schedule = _unpack(spaceVector)
     cmd = "fu{0}d{1}bx{2}y{3}sn{4}u{5}".format(step, dist, blockSize[0], blockSize[1], sn, s_unroll)
     cmd += ("bmx{0}" if blockMergeX else "cmx{0}").format(mergeFactorX)
     cmd += ("bmy{0}" if blockMergeY else "cmy{0}").format(mergeFactorY)
     cmd += "mf{0}".format(m_threshold)
     if prefetch:
         cmd += "p" if int(prefetch) == 1 else "p{0}".format(int(prefetch))
-    cmd += "x" + xrim[0] + "m" + str(xcd) + ("t" if temporal else "") + ("s" if streaming else "")
+    cmd += "x" + xrim[0] + "m" + str(xcd) + ("t" if temporal else "") + ("s" if streaming else "") + ("r" if schedule == "reuse" else "")
     return cmd
 
 
@@ -165,10 +192,63 @@ def enumerate_space(steps=(1,), full=False):
         if ndim == 2 and v[14]:
             if v[2][1] != 1 or v[8] != 1:
                 continue           # 2D --streaming ignores by / y merging (codegen_2d.hpp:125)
-        v = tuple(v)
-        if FilterParams(v):
-            out.append(v)
+        cands = [tuple(v) + ("scatter",)]
+        # the reference sweeps dist over its legal range (tuning.py:110-112): each value is a different split between
+        # resident source planes and carried partial sums (--schedule reuse)
+        for d in range(max(1, (v[0] - 1) * order), v[0] * order + 1):
+            cands.append(tuple(v[:1] + [d] + v[2:]) + ("reuse",))
+        for c in cands:
+            if FilterParams(c):
+                out.append(c)
     return out
+
+
+# ---- register model -----------------------------------------------------------------------------------------------
+# P(the kernel spills to scratch and is refused by the runtime) from what the generator knows before compiling: a logistic
+# model fitted to hipcc's resource reports of 550 random configurations of the 3D / 2D spaces (scripts/fit_reg_model.py ->
+# profiles/r02_reg_model.md).  Dropping configurations with P > 0.6 leaves 9.6 % of the compiled ones refused (28 % without
+# the filter; round 1: 45 % of the random 3D ones) for 4.3 % of the usable ones lost.
+SPILL_BIAS = -5.8552
+SPILL_W = [9.5442, -0.5771, -1.4978, 0.2913, -15.0436]
+SPILL_THRESHOLD = 0.6
+
+
+def lane_register_budget(threads):
+    """Registers per lane (VGPR + AGPR file of 512 per SIMD lane) when one whole workgroup has to be resident on a CU."""
+    waves_per_simd = -(-(-(-threads // 64)) // 4)
+    return 512 // max(1, waves_per_simd) // 8 * 8
+
+
+def spill_features(demand, threads, taps, pts, stages, words):
+    b = float(lane_register_budget(threads))
+    return [demand / b, words * taps * pts * stages / b, 1.0 if stages > 1 else 0.0, words - 1.0, words * pts / b]
+
+
+def spill_probability(info):
+    """info = the generator's kernel info (drs_plugin_info JSON of the emitted source)."""
+    import math
+    x = spill_features(info["reg_demand"], info["threads"], info["taps"], info["points_per_lane"], info["stages"], 1 if info["dtype"] == "fp32" else 2)
+    z = SPILL_BIAS + sum(w * v for w, v in zip(SPILL_W, x))
+    return 1.0 / (1.0 + math.exp(-z))
+
+
+def kernel_info(args):
+    """The kernel info the generator embeds in the emitted source (no compilation), or None when it rejects the configuration."""
+    import re
+    import drstencil_amd as drs
+    rc, _msg, src = drs.generate(list(args))
+    if rc != 0 or not src:
+        return None
+    m = re.search(r'return "(\{.*\})";', src)
+    return json.loads(m.group(1).replace('\\"', '"')) if m else None
+
+
+def registerFilter(args):
+    """False when the configuration is predicted to spill to scratch (it would be compiled only to be refused)."""
+    info = kernel_info(args)
+    if info is None:
+        return True            # let the build report the generator's own error
+    return spill_probability(info) <= SPILL_THRESHOLD
 
 
 def getElapsedTime(start, end):
@@ -195,14 +275,70 @@ def _noop(_):
     return os.getpid()
 
 
-def searchSpace(stc, is3d, dtype, configs, outdir, iterations=8, budget_s=None, jobs=16, extra_opts=()):
+def verify(kern, torch, A, B, G):
+    """One launch of dr_ and one of gold_ from the same input: (ok, max relative difference).  Single-pass kernels keep the
+    gold order as an FMA chain and must agree bit for bit; temporal pipelines re-associate: 1e-6 (fp32) / 1e-12 (fp64)."""
+    B.zero_(); G.zero_()
+    kern.launch(A.data_ptr(), B.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    kern.launch_gold(A.data_ptr(), G.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    if torch.equal(B, G):
+        return True, 0.0
+    h = kern.info["halo"]
+    inner = tuple(slice(h, d - h) for d in A.shape)
+    rel = float(((B[inner] - G[inner]).abs() / G[inner].abs().clamp_min(1e-30)).max())
+    outside_equal = int(torch.count_nonzero(B)) == int(torch.count_nonzero(B[inner]))
+    tol = 1e-6 if A.dtype == torch.float32 else 1e-12
+    return (kern.info.get("stages", 1) > 1 and rel <= tol and outside_equal), rel
+
+
+def _profile_one(job):
+    """The reference's per-configuration flow (benchmarks/3d7pt_star/tuning.py:132-137) for one configuration, in a clean
+    worker process: ./drstencil <cfg> --check -o ./cu/<name>.hip x.stc ; compile_run.sh <name> ; getGpuMetrics.py <name>."""
+    import shutil
+    import subprocess
+    import drstencil_amd as drs
+    name, args, workdir = job
+    here = os.path.dirname(os.path.abspath(__file__))
+    os.makedirs(os.path.join(workdir, "cu"), exist_ok=True)
+    shutil.copy(os.path.join(drs.SUPPORT_DIR, "common.hpp"), os.path.join(workdir, "cu"))
+    stc = args[-1]
+    shutil.copy(stc, workdir)
+    log = []
+    env = dict(os.environ, TMPDIR="/tmp")
+    for cmd in ([drs.CLI_PATH] + list(args[:-1]) + ["--check", "-o", "./cu/%s.hip" % name, os.path.basename(stc)],
+                ["bash", os.path.join(here, "compile_run.sh"), name],
+                [sys.executable, os.path.join(here, "getGpuMetrics.py"), name]):
+        r = subprocess.run(cmd, cwd=workdir, env=env, capture_output=True, text=True, timeout=900)
+        log.append("[%s rc=%d] %s" % (os.path.basename(cmd[1] if cmd[0] in ("bash", sys.executable) else cmd[0]), r.returncode, (r.stdout + r.stderr)[-300:].strip()))
+        if r.returncode != 0:
+            return name, False, "\n".join(log)
+    return name, True, "\n".join(log)
+
+
+def rocprof_metrics(pool, winners, outdir):
+    """Profile the best configurations like the reference profiles every one: duration, FETCH_SIZE / WRITE_SIZE traffic, the
+    program's own check result and the compiler's resource report, one row each in <outdir>/gpuMetrics.csv.  Runs in the
+    pool's worker processes (started before this process touched HIP), one after the other: the profiler wants the GPU alone."""
+    rows = []
+    for name, args in winners:
+        name, ok, log = pool.submit(_profile_one, (name, args, outdir)).result()
+        print("profiled {0}: {1}".format(name, "ok" if ok else "FAILED\n" + log), flush=True)
+        rows.append((name, ok))
+    return rows
+
+
+def searchSpace(stc, is3d, dtype, configs, outdir, iterations=8, budget_s=None, jobs=16, extra_opts=(), profile_top=0, keep_loaded=False):
     """Sweep `configs` (space vectors or raw option strings).
 
+    Before anything is compiled, registerFilter() drops configurations whose per-lane state cannot fit the register file.
     Generation + compilation (hipcc) runs in worker processes that are started from a fork SERVER before
     this process touches the GPU -- a process that has initialised HIP must not fork/exec compilers, the
     clean workers may at any time -- and overlaps with the timing of the configurations already built.
-    Improvements go to duration.log (seconds-since-start, best ns, name), every result to results.jsonl;
-    a wall-clock budget (the reference's 2D tuner stops after 3600 s) ends the sweep cleanly."""
+    Every result goes to results.jsonl; a configuration becomes the recorded best (duration.log: seconds-since-start,
+    best ns, name) only after its output has been compared with the emitted gold kernel; each plugin is unloaded after
+    its measurement.  A wall-clock budget (the reference's 2D tuner stops after 3600 s) ends the sweep cleanly; the best
+    `profile_top` configurations then go through rocprof_metrics()."""
     import multiprocessing
     from concurrent.futures import ProcessPoolExecutor
     os.makedirs(outdir, exist_ok=True)
@@ -215,6 +351,9 @@ def searchSpace(stc, is3d, dtype, configs, outdir, iterations=8, budget_s=None, 
             named.append((cfgToString(c), cfgToCommandLine(c).split()))
     base = (["--3d"] if is3d else []) + ["--dtype", dtype] + list(extra_opts)
     jobsl = [(n, base + a + [stc]) for n, a in named]
+    nall = len(jobsl)
+    jobsl = [j for j in jobsl if registerFilter(j[1])]
+    print("{0} configurations, {1} dropped by the register model before compiling".format(nall, nall - len(jobsl)), flush=True)
     argmap = dict(jobsl)
     t_start = time.time()
     pool = ProcessPoolExecutor(max_workers=jobs, mp_context=multiprocessing.get_context("forkserver"))
@@ -223,11 +362,11 @@ def searchSpace(stc, is3d, dtype, configs, outdir, iterations=8, budget_s=None, 
 
     import drstencil_amd as drs
     torch = None
-    A = B = None
+    A = B = G = None
     best = 1e18
     results = []
     esz = 4 if dtype == "fp32" else 8
-    nfail = 0
+    nfail = nwrong = 0
     for cnt, fut in enumerate(futures, 1):
         name, ok, info = fut.result()
         if not ok:
@@ -243,14 +382,29 @@ def searchSpace(stc, is3d, dtype, configs, outdir, iterations=8, budget_s=None, 
             tdt = torch.float32 if dtype == "fp32" else torch.float64
             A = torch.rand(shape, dtype=tdt, device="cuda")
             B = torch.zeros_like(A)
+            G = torch.zeros_like(A)
         dur = measure(kern, torch, A, B, iterations)
         gbs = 2.0 * esz * A.numel() / dur
         gst = kern.updates_per_launch() / dur
         rec = dict(name=name, args=" ".join(argmap[name][:-1]), duration_ns=dur, GBps=gbs, frac=gbs / 8000.0, GStencil=gst,
-                   lds=kern.info["lds_bytes"], threads=kern.info["threads"], step=kern.info["step"])
+                   lds=kern.info["lds_bytes"], threads=kern.info["threads"], step=kern.info["step"], schedule=kern.info.get("schedule"),
+                   vgprs=kern.resources.get("vgprs"), agprs=kern.resources.get("agprs"), reg_demand=kern.info.get("reg_demand"))
+        if dur < best:
+            # a configuration is recorded as the best only if it computes what the gold kernel computes
+            good, rel = verify(kern, torch, A, B, G)
+            rec["verified"], rec["max_rel_vs_gold"] = bool(good), rel
+            A.uniform_()                                # the check overwrote B; fresh input for the next measurement
+            if not good:
+                nwrong += 1
+                rec["duration_ns_unverified"] = rec.pop("duration_ns")
+                print("{0}/{1}: {2} WRONG RESULT (max rel {3:.3g} vs gold): dropped".format(cnt, len(jobsl), name, rel), flush=True)
         results.append(rec)
         with open(os.path.join(outdir, "results.jsonl"), "a") as f:
             f.write(json.dumps(rec) + "\n")
+        if not keep_loaded:
+            kern.unload()                               # thousands of code objects would otherwise stay mapped
+        if "duration_ns" not in rec:
+            continue
         print("{0}/{1}: {2}  {3:.0f} ns  {4:.0f} GB/s ({5:.1f}%)  {6:.1f} GStencil/s".format(
             cnt, len(jobsl), name, dur, gbs, gbs / 80.0, gst), flush=True)
         if dur < best:
@@ -262,11 +416,18 @@ def searchSpace(stc, is3d, dtype, configs, outdir, iterations=8, budget_s=None, 
             for f in futures[cnt:]:
                 f.cancel()
             break
-    pool.shutdown(wait=False, cancel_futures=True)
     with open(os.path.join(outdir, "duration.log"), "a") as f:
         f.write(str((datetime.datetime.now() - startTime).seconds) + " s, " + str(int(best)) + "\n")
     # the reference minimises Duration for a fixed step; across steps the objective is updates per second
+    results = [r for r in results if "duration_ns" in r]
     results.sort(key=lambda r: -r["GStencil"])
+    print("{0} timed, {1} build failures, {2} wrong results dropped".format(len(results), nfail, nwrong), flush=True)
+    if profile_top and results:
+        del A, B, G
+        if torch is not None:
+            torch.cuda.empty_cache()
+        rocprof_metrics(pool, [(r["name"], argmap[r["name"]]) for r in results[:profile_top]], outdir)
+    pool.shutdown(wait=False, cancel_futures=True)
     return results
 
 
@@ -284,6 +445,8 @@ def main():
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--list", action="store_true", help="only print the space size and the first configs")
     ap.add_argument("--configs-file", default=None, help="file with one raw option string per line instead of the space")
+    ap.add_argument("--profile-top", type=int, default=0, help="after the search: rocprofv3 counters of the best N configurations -> <out>/gpuMetrics.csv (reference flow)")
+    ap.add_argument("--jobs", type=int, default=16, help="compile workers")
     a = ap.parse_args()
     order, ndim, elem_bytes = a.order, (3 if a.is3d else 2), (4 if a.dtype == "fp32" else 8)
     if a.configs_file:
@@ -299,7 +462,7 @@ def main():
         for p in paras[:5]:
             print(cfgToString(p) if not isinstance(p, str) else p, "|", cfgToCommandLine(p) if not isinstance(p, str) else "")
         return
-    res = searchSpace(os.path.abspath(a.stc), a.is3d, a.dtype, paras, a.out, budget_s=a.budget or None)
+    res = searchSpace(os.path.abspath(a.stc), a.is3d, a.dtype, paras, a.out, budget_s=a.budget or None, jobs=a.jobs, profile_top=a.profile_top)
     print("best:")
     for r in res[:10]:
         print("  {name}  {duration_ns:.0f} ns  {GBps:.0f} GB/s  {GStencil:.1f} GStencil/s".format(**r))

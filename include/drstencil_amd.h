@@ -50,12 +50,20 @@ void drs_spec_partition(const drs_spec *s, int sizes[4]);
  * cache_dir (NULL: <package>/_kcache) unless already cached, and load.  NULL on failure with
  * *log (malloc'ed, may be NULL) holding the generator messages / compiler output. */
 drs_kernel *drs_kernel_build(int argc, const char *const *argv, const char *cache_dir, char **log);
-void drs_kernel_close(drs_kernel *k);
+void drs_kernel_close(drs_kernel *k);                /* frees the handle; the plugin stays mapped (safe at process exit) */
+/* drs_kernel_close + the plugin is unloaded (hipDeviceSynchronize, then dlclose: its code object leaves the HIP runtime).
+ * For long sweeps that load thousands of kernels (the tuner: benchmarks/3d7pt_star/tuning.py:102-142 starts one process
+ * per configuration instead).  Not to be called while one of its launches may still be running on another device. */
+int drs_kernel_unload(drs_kernel *k);
 const char *drs_kernel_info(const drs_kernel *k);   /* JSON: dims, dtype, halo, step, grid, lds ... */
 const char *drs_kernel_path(const drs_kernel *k);   /* the loaded shared object */
 /* JSON: vgprs, agprs, sgprs, scratch_bytes_per_lane, sgpr_spill, vgpr_spill, occupancy_waves_per_simd, lds_bytes of
- * dr_<name> as reported by hipcc (what the reference reads from `ncu --set full`, getGpuMetrics.py:9).  A kernel that
- * spills to scratch is refused by drs_kernel_build (NULL + log) unless DRS_ALLOW_SCRATCH=1. */
+ * dr_<name> (with --pair-launch: the maximum over dr_<name> and dr2_<name>) as reported by hipcc -- what the reference reads
+ * from `ncu --set full`, getGpuMetrics.py:9 -- plus "verified": 1 when every field was found in the compiler's report.
+ * drs_kernel_build refuses (NULL + log): a kernel that spills to scratch (DRS_ALLOW_SCRATCH=1 overrides), a kernel whose
+ * report could not be read (DRS_ALLOW_UNVERIFIED=1), a cache miss once this process has launched a kernel or when
+ * DRS_NO_COMPILE=1 (hipcc is a child process: build first, launch afterwards), and --debug-drop-barrier kernels
+ * (wrong results by design) without DRS_EXPERIMENTS=1. */
 const char *drs_kernel_resources(const drs_kernel *k);
 /* one launch of dr_<name><<<grid, block, 0, stream>>>(in, out): codegen.hpp:577,582-583 */
 int drs_kernel_launch(drs_kernel *k, const void *d_in, void *d_out, void *stream);

@@ -87,7 +87,7 @@ def _run_tuner_smoke():
     os.makedirs(out, exist_ok=True)
     try:
         r = subprocess.run([sys.executable, os.path.join(ROOT, "drstencil_amd", "tuner", "tuning.py"), os.path.join(ROOT, "tests", "stc", "t3_star.stc"),
-                            "--3d", "--dtype", "fp32", "--steps", "1,2", "--max-configs", "6", "--seed", "3", "--out", out],
+                            "--3d", "--dtype", "fp32", "--steps", "1,2", "--max-configs", "6", "--seed", "3", "--out", out, "--profile-top", "1"],
                            capture_output=True, text=True, timeout=600)
         text = "[tuner rc=%d]\n%s%s" % (r.returncode, r.stdout[-4000:], r.stderr[-2000:])
     except Exception as e:
@@ -109,7 +109,7 @@ def _run_reference_flow(drs):
     os.makedirs(os.path.join(out, "cu"))
     shutil.copy(os.path.join(drs.SUPPORT_DIR, "common.hpp"), os.path.join(out, "cu"))
     shutil.copy(os.path.join(ROOT, "tests", "stc", "t3_star.stc"), out)
-    name = "fu2d2bx64y4sn16u4bmx4bmy2mf5pxdm2"
+    name = "fu2d2bx64y4sn16u4bmx4bmy2mf5pxdm2r"       # --dist 2 on the command line: the reuse schedule
     log = []
     try:
         env = dict(os.environ, TMPDIR="/tmp")

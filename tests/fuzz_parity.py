@@ -37,6 +37,16 @@ def make_jobs(n, seed):
                     cl.append("--streaming")
                 if "--prefetch-depth" in cl:
                     cl[cl.index("--prefetch-depth") + 1] = str(random.choice([1, 2, 3, 4]))
+                # round-2 knobs: the reuse schedule's --merge-forward on both sides of the retained planes' tap counts, and the
+                # memory path (unconditional / window loads, buffer-masked stores, drains)
+                if "--schedule" not in cl and random.random() < 0.6:
+                    cl[cl.index("--merge-forward") + 1] = str(random.choice([0, 2, 3, 100]))
+                if random.random() < 0.3:
+                    cl += ["--uniform-loads", str(random.choice([1, 2]))]
+                if random.random() < 0.3:
+                    cl += ["--store-mask", "buffer"]
+                if random.random() < 0.2:
+                    cl += ["--drain", str(random.choice([1, 2]))]
                 args = (["--3d"] if ndim == 3 else []) + ["--dtype", dtype] + cl + [stc]
                 jobs.append((ndim, stc, dtype, args, v[0]))
     return jobs

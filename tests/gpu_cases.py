@@ -49,6 +49,27 @@ _add("2d25_fp64_step2", 2, "t2_box25", "--dtype", "fp64", "--step", "2")
 _add("2dodd_fp32_it5", 2, "t2_odd", "--dtype", "fp32")
 _add("2dodd_fp64_step2_stream", 2, "t2_odd", "--dtype", "fp64", "--step", "2", "--streaming")
 
+# --dist / --merge-forward as real knobs: an explicit --dist selects --schedule reuse (`Range` source planes in register
+# windows, partial sums carried over the rest); one case per legal value (step-1)*order <= dist <= step*order
+# (benchmarks/3d7pt_star/tuning.py:20), --merge-forward on both sides of the retained planes' in-plane tap counts
+_add("3d7_fp32_s1_dist1", 3, "t3_star", "--dtype", "fp32", "--dist", "1", "--sn", "8")
+_add("3d7_fp32_s2_dist1", 3, "t3_star", "--dtype", "fp32", "--step", "2", "--dist", "1", "--sn", "16", "--prefetch")
+_add("3d7_fp32_s2_dist2", 3, "t3_star", "--dtype", "fp32", "--step", "2", "--dist", "2", "--sn", "16", "--prefetch")
+_add("3d7_fp64_s2_dist1_mf0", 3, "t3_star", "--dtype", "fp64", "--step", "2", "--dist", "1", "--merge-forward", "0", "--sn", "9")
+_add("3d7_fp32_s2_dist2_mf2_lds", 3, "t3_star", "--dtype", "fp32", "--step", "2", "--dist", "2", "--merge-forward", "2", "--xrim", "lds", "--sn", "32")
+_add("3d7_fp32_s3_dist2", 3, "t3_star", "--dtype", "fp32", "--step", "3", "--dist", "2", "--sn", "16")
+_add("3d7_fp32_s3_dist3", 3, "t3_star", "--dtype", "fp32", "--step", "3", "--dist", "3", "--sn", "16")
+_add("3dodd_fp64_s2_dist2", 3, "t3_odd", "--dtype", "fp64", "--step", "2", "--dist", "2")
+_add("2d5_fp32_s2_stream_dist1", 2, "t2_star", "--dtype", "fp32", "--step", "2", "--dist", "1", "--streaming", "--prefetch")
+_add("2d25_fp64_stream_dist2_mf0", 2, "t2_box25", "--dtype", "fp64", "--streaming", "--dist", "2", "--merge-forward", "0")
+_add("3d7_fp32_window", 3, "t3_star", "--dtype", "fp32", "--step", "2", "--schedule", "window", "--sn", "16", "--prefetch")
+# memory-path knobs (round 2): exact vmcnt pipeline -- unconditional loads (re-read / closed window), buffer-masked stores, drains
+_add("3d7_fp32_s2_ul1_buf", 3, "t3_star", "--dtype", "fp32", "--step", "2", "--sn", "16", "--prefetch", "--prefetch-depth", "3", "--uniform-loads", "1", "--store-mask", "buffer", "--cc-opt", "-fno-slp-vectorize")
+_add("3d7_fp64_ul2_buf_drain1", 3, "t3_star_odd", "--dtype", "fp64", "--sn", "5", "--prefetch", "--prefetch-depth", "2", "--uniform-loads", "2", "--store-mask", "buffer", "--drain", "1")
+_add("3d7_fp32_t2_ul2_drain2", 3, "t3_star", "--dtype", "fp32", "--step", "2", "--temporal", "1", "--by", "8", "--block-merge-y", "4", "--sn", "16", "--prefetch", "--uniform-loads", "2", "--drain", "2")
+_add("2d25_fp32_stream_buf", 2, "t2_box25", "--dtype", "fp32", "--streaming", "--prefetch", "--uniform-loads", "2", "--store-mask", "buffer")
+_add("2d5_fp64_tile_buf", 2, "t2_star", "--dtype", "fp64", "--store-mask", "buffer")
+
 # temporal blocking (on-chip multi-step): equal to the fused stencil up to rounding
 _add("3d7_fp32_t2", 3, "t3_star", "--dtype", "fp32", "--step", "2", "--temporal", "1", "--by", "8", "--block-merge-y", "4", "--sn", "16", "--prefetch")
 _add("3d7_fp64_t2_lds", 3, "t3_star", "--dtype", "fp64", "--step", "2", "--temporal", "1", "--by", "8", "--block-merge-y", "4", "--sn", "9", "--xrim", "lds")
@@ -59,6 +80,13 @@ _add("3dodd_fp32_t2_falls_back_to_fused", 3, "t3_odd", "--dtype", "fp32", "--ste
 _add("2d5_fp32_t2_tile", 2, "t2_star", "--dtype", "fp32", "--step", "2", "--temporal", "1", "--by", "8", "--block-merge-y", "4")
 _add("2d5_fp64_t3_stream", 2, "t2_star", "--dtype", "fp64", "--step", "3", "--temporal", "1", "--streaming", "--sn", "24", "--prefetch")
 _add("2d25_fp64_t2_tile", 2, "t2_box25", "--dtype", "fp64", "--step", "2", "--temporal", "1", "--by", "8", "--block-merge-y", "4")
+
+# how far the re-association of on-chip time steps drifts from the fused arithmetic: 100 iterations (the tight case of SURVEY section 7)
+TEMPORAL_MARGIN = [
+    ("t2_fp32_it100", 3, stc("t3_star_it100"), ["--3d", "--dtype", "fp32", "--step", "2", "--temporal", "1", "--by", "8", "--block-merge-y", "4", "--sn", "16", "--prefetch"]),
+    ("t3_fp32_it100", 3, stc("t3_star_it100"), ["--3d", "--dtype", "fp32", "--step", "3", "--temporal", "1", "--bx", "34", "--by", "15", "--block-merge-y", "2", "--sn", "16", "--prefetch"]),
+    ("fused2_fp32_it100", 3, stc("t3_star_it100"), ["--3d", "--dtype", "fp32", "--step", "2", "--sn", "16"]),
+]
 
 SMOKE = ("smoke3", 3, stc("smoke3"), ["--3d", "--dtype", "fp32"])
 
@@ -89,6 +117,10 @@ def _bench_kernels():
 
 
 _bench_kernels()
+# the reference's legal --dist range on the headline geometry at full size (different kernels, identical results)
+for _d in ("1", "2"):
+    FULL.append(("C4_3d7pt_1024_fp32_fused2_dist%s" % _d, 3, os.path.join(CFG, "c4_3d7pt_star_1024.stc"),
+                 ["--3d", "--dtype", "fp32", "--step", "2", "--dist", _d, "--prefetch", "--bx", "32", "--by", "16", "--block-merge-x", "4", "--block-merge-y", "2", "--sn", "32", "--xcd-remap", "2"]))
 
 # BASELINE config C4 AS WRITTEN ("z-slab decomposition across 8 x MI355X"): the slab-view and pair-launch kernels that
 # bench.py --gpus 2/4/8 launches, at 1024^3, every rank in turn on one GPU (tests/test_gpu_parity.py::test_c4_slab_views_at_full_size)
@@ -100,7 +132,7 @@ C1 = ("C1_2d5pt_4096_fp32_it100", 2, os.path.join(CFG, "c1_2d5pt_star_4096.stc")
 
 
 def all_build_args():
-    out = [c[3] + [c[2]] for c in SMALL] + [SMOKE[3] + [SMOKE[2]]] + [c[3] + [c[2]] for c in FULL] + [C1[3] + [C1[2]]]
+    out = [c[3] + [c[2]] for c in SMALL] + [SMOKE[3] + [SMOKE[2]]] + [c[3] + [c[2]] for c in FULL] + [C1[3] + [C1[2]]] + [c[3] + [c[2]] for c in TEMPORAL_MARGIN]
     return out
 
 

@@ -132,3 +132,17 @@ def test_emitted_stdout_protocol_strings(tmp_path):
               "Checking error ...", "[Test] RMS Error: %e", "#include \"common.hpp\"", "hipcc" if False else "hip_runtime"):
         assert s in src
     assert "atomicAdd" not in src and "__HIP_PLATFORM" not in src
+
+
+def test_temporal_fallback_is_reported(tmp_path):
+    """--temporal 1 on a stencil whose fused coefficients do not survive the 6-digit rounding (drstencil.hpp:192) cannot equal
+    the reference's fused arithmetic, so the fused single-pass kernel is emitted -- and the user is told (stdout note +
+    banner), not left to find stages == 1 in the kernel info."""
+    import drstencil_amd as drs
+    stc = os.path.join(ROOT, "tests", "stc", "t3_odd.stc")
+    rc, msg, src = drs.generate(["--3d", "--dtype", "fp32", "--step", "2", "--temporal", "1", stc])
+    assert rc == 0 and src
+    assert "note: --temporal 1 ignored" in msg and "// note: --temporal 1 ignored" in src
+    assert '\\"stages\\":1' in src
+    rc, msg, src = drs.generate(["--3d", "--dtype", "fp32", "--step", "2", "--temporal", "1", os.path.join(ROOT, "tests", "stc", "t3_star.stc")])
+    assert rc == 0 and "note:" not in msg and '\\"stages\\":2' in src

@@ -239,6 +239,15 @@ def _emulated_fuzz_jobs(n=14, seed=9):
                 cl = t.cfgToCommandLine(v).split()
                 if "--prefetch-depth" in cl:
                     cl[cl.index("--prefetch-depth") + 1] = str(rnd.choice([1, 2, 3]))
+                # round-2 knobs: --merge-forward on both sides of the retained planes' tap counts (reuse schedule), memory path
+                if "--schedule" not in cl and rnd.random() < 0.6:
+                    cl[cl.index("--merge-forward") + 1] = str(rnd.choice([0, 2, 3, 100]))
+                if rnd.random() < 0.3:
+                    cl += ["--uniform-loads", str(rnd.choice([1, 2]))]
+                if rnd.random() < 0.3:
+                    cl += ["--store-mask", "buffer"]
+                if rnd.random() < 0.2:
+                    cl += ["--drain", str(rnd.choice([1, 2]))]
                 jobs.append((t.cfgToString(v) + "_" + dtype + "_%dd" % ndim + pts.lower(), ndim, pts, dims, (["--3d"] if ndim == 3 else []) + ["--dtype", dtype] + cl, v[0]))
     return jobs
 
