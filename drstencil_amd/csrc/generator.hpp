@@ -95,6 +95,9 @@ MI355X options:
                         1 and 2 leave no vector-memory instruction under a branch: exact s_waitcnt vmcnt(N) pipelining.
 --store-mask <branch|buffer>  branch (default): guarded global stores; buffer: buffer stores whose per-lane offset is out of
                         range where the lane must not store (no branch).
+--stage <reg|dma>       How an arriving plane reaches LDS in streaming kernels: reg (default) = global loads into VGPRs
+                        (software prefetch) + LDS writes; dma = LDS-DMA (global_load_lds_dwordx4) straight into the plane's
+                        LDS slot, one plane ahead, no prefetch registers (16-byte vectors, block y merging, one stage).
 --drain <0|1|2>         s_waitcnt vmcnt(0) before every plane's prefetch loads (1) or before its LDS staging (2).
 --cc-opt <flag>         Extra hipcc flag for this kernel (repeatable), e.g. --cc-opt -fno-slp-vectorize.
 --clamp-loads <0|1>     1 (default): branch-free loads -- lanes outside the grid read the plane origin (their
@@ -169,6 +172,7 @@ inline GenResult generate(const std::vector<std::string> &args /* argv[1..] */) 
         else if (a == "--drain") { if (!int_opt(o.drain, nullptr)) break; }
         else if (a == "--uniform-loads") { if (!int_opt(o.uniform_loads, nullptr)) break; }
         else if (a == "--store-mask") { if (!str_opt(o.store_mask)) break; }
+        else if (a == "--stage") { if (!str_opt(o.stage)) break; }
         else if (a == "--cc-opt") { std::string f; if (!str_opt(f)) break; o.cc_opts.push_back(f); }
         else if (a == "--lazy-rims") { if (!int_opt(o.lazy_rims, nullptr)) break; }
         else if (a == "--xcd-remap") { if (!int_opt(o.xcd_remap, nullptr)) break; }
@@ -185,6 +189,7 @@ inline GenResult generate(const std::vector<std::string> &args /* argv[1..] */) 
     if (!o.schedule_set && o.dist != 0) o.schedule = "reuse";
     if (o.schedule != "scatter" && o.schedule != "window" && o.schedule != "reuse") { res.messages += "Illegal input.\n"; res.exit_code = 255; return res; }
     if (o.xrim != "lds" && o.xrim != "dpp") { res.messages += "Illegal input.\n"; res.exit_code = 255; return res; }
+    if (o.stage != "reg" && o.stage != "dma") { res.messages += "Illegal input.\n"; res.exit_code = 255; return res; }
     if (o.store_mask != "buffer" && o.store_mask != "branch") { res.messages += "Illegal input.\n"; res.exit_code = 255; return res; }
     if (o.step < 1) { res.messages += "Illegal input.\n"; res.exit_code = 255; return res; }
 

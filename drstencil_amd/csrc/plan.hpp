@@ -88,6 +88,9 @@ struct GenOptions {
                                  // block's last plane they re-read it); 2: unconditionally through a buffer window that closes past the last
                                  // plane (the loads then move nothing).  1 and 2 leave no vector-memory instruction of the loop under a
                                  // branch, so the compiler's s_waitcnt vmcnt(N) counts are exact
+    std::string stage = "reg";   // how an arriving plane gets into LDS: reg = global loads into VGPRs (software prefetch), then ds_write;
+                                 // dma = LDS-DMA (global_load_lds_dwordx4): the plane lands in its LDS slot without touching VGPRs, one plane
+                                 // ahead of the one being summed (look-ahead costs an LDS slot instead of prefetch register sets)
     std::vector<std::string> cc_opts;   // --cc-opt <flag> (repeatable): extra hipcc flags for this kernel (e.g. -fno-slp-vectorize); part of the
                                  // kernel's identity: printed in the banner's build line and applied by drs_kernel_build
     std::string store_mask = "branch";  // branch: plain global stores under per-lane guards (default: measured faster);
@@ -135,6 +138,7 @@ struct KernelPlan {
     int UN = 1;              // unroll of the streaming loop
     bool prefetch = false;
     int PD = 1;              // prefetch depth (planes in flight)
+    bool dma = false;        // --stage dma: planes are staged by LDS-DMA into a per-lane-dense LDS image (emit_hip.hpp)
     std::string error;       // non-empty: invalid configuration
     std::string note;        // non-empty: something the user asked for was not done (printed by the generator, kept in the banner)
 };

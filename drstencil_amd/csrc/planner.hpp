@@ -197,6 +197,18 @@ inline KernelPlan make_plan(const Stencil &st, const GenOptions &o_in, const std
     p.NBS = p.has_s ? std::max(1, ceil_div(p.DS - 2 * H, p.SN)) : 1;
     if (p.DX - 2 * H < 1 || (p.has_y && p.DY - 2 * H < 1) || (p.has_s && p.DS - 2 * H < 1)) { p.error = "grid has no interior"; return p; }
 
+    if (o.stage == "dma") {
+        // LDS-DMA writes 64 lanes x 16 bytes of one wavefront instruction to consecutive LDS addresses: the LDS image is
+        // dense per (row, vector, lane) and the halo pieces dense per loader task (emit_hip.hpp); what that needs:
+        if (!p.has_s) { p.error = "--stage dma is for streaming kernels"; return p; }
+        if (p.stages > 1) { p.error = "--stage dma: on-chip stages exchange through LDS writes"; return p; }
+        if (p.VL * (p.fp32 ? 4 : 8) != 16) { p.error = "--stage dma needs 16-byte vectors (N and the x merge factor multiples of 4 fp32 / 2 fp64)"; return p; }
+        if (p.cyclic_y) { p.error = "--stage dma needs block y merging"; return p; }
+        if (!o.clamp_loads || o.halo_spread) { p.error = "--stage dma needs --clamp-loads 1 --halo-spread 0"; return p; }
+        if (p.has_y && !p.exact_y) { p.error = "--stage dma needs --exact-y 1"; return p; }
+        p.dma = true;
+        p.prefetch = false;      // the look-ahead is the DMA itself
+    }
     p.SROW = p.PADL + p.TX + p.PADR + o.lds_pad;
     p.SROWS = p.has_y ? p.TY + p.hym + p.hyp : 1;
     if (p.stages > 1) p.NSLOT = p.stages;

@@ -320,11 +320,16 @@ def rocprof_metrics(pool, winners, outdir):
     """Profile the best configurations like the reference profiles every one: duration, FETCH_SIZE / WRITE_SIZE traffic, the
     program's own check result and the compiler's resource report, one row each in <outdir>/gpuMetrics.csv.  Runs in the
     pool's worker processes (started before this process touched HIP), one after the other: the profiler wants the GPU alone."""
+    import shutil
     rows = []
+    work = os.path.join(outdir, "profile")     # cu/ bin/ prof/ and the flow's own duration.log live here, not beside the search's logs
+    os.makedirs(work, exist_ok=True)
     for name, args in winners:
-        name, ok, log = pool.submit(_profile_one, (name, args, outdir)).result()
+        name, ok, log = pool.submit(_profile_one, (name, args, work)).result()
         print("profiled {0}: {1}".format(name, "ok" if ok else "FAILED\n" + log), flush=True)
         rows.append((name, ok))
+    if os.path.exists(os.path.join(work, "gpuMetrics.csv")):
+        shutil.copy(os.path.join(work, "gpuMetrics.csv"), os.path.join(outdir, "gpuMetrics.csv"))
     return rows
 
 

@@ -47,6 +47,8 @@ def make_jobs(n, seed):
                     cl += ["--store-mask", "buffer"]
                 if random.random() < 0.2:
                     cl += ["--drain", str(random.choice([1, 2]))]
+                if random.random() < 0.3 and "--temporal" not in cl and "--cyclic-merge-y" not in cl and (ndim == 3 or "--streaming" in cl):
+                    cl += ["--stage", "dma"]
                 args = (["--3d"] if ndim == 3 else []) + ["--dtype", dtype] + cl + [stc]
                 jobs.append((ndim, stc, dtype, args, v[0]))
     return jobs

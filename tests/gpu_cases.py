@@ -70,6 +70,21 @@ _add("3d7_fp32_t2_ul2_drain2", 3, "t3_star", "--dtype", "fp32", "--step", "2", "
 _add("2d25_fp32_stream_buf", 2, "t2_box25", "--dtype", "fp32", "--streaming", "--prefetch", "--uniform-loads", "2", "--store-mask", "buffer")
 _add("2d5_fp64_tile_buf", 2, "t2_star", "--dtype", "fp64", "--store-mask", "buffer")
 
+# --stage dma (round 2): planes staged by LDS-DMA (global_load_lds_dwordx4) into the per-lane-dense LDS image, tile-edge lanes re-reading
+# from the halo regions; every schedule, both x-rim paths, box corners, wide halos (hx > points per lane), ragged grids
+_add("3d7_fp64_dma", 3, "t3_star", "--dtype", "fp64", "--stage", "dma", "--sn", "8")
+_add("3d7_fp64_dma_s2", 3, "t3_star", "--dtype", "fp64", "--step", "2", "--stage", "dma", "--sn", "16", "--bx", "32", "--by", "8", "--block-merge-y", "2")
+_add("3dodd_fp32_dma_s2", 3, "t3_odd", "--dtype", "fp32", "--step", "2", "--stage", "dma", "--sn", "9")
+_add("3d9x_fp32_dma_lds", 3, "t3_cross", "--dtype", "fp32", "--dist", "2", "--schedule", "scatter", "--stage", "dma", "--xrim", "lds")
+_add("3dodd_fp32_dma_reuse_d1", 3, "t3_odd", "--dtype", "fp32", "--step", "2", "--dist", "1", "--stage", "dma")
+_add("3d7_fp64_dma_reuse_d2_mf0", 3, "t3_star", "--dtype", "fp64", "--step", "2", "--dist", "2", "--merge-forward", "0", "--stage", "dma", "--sn", "5")
+_add("3dodd_fp32_dma_window", 3, "t3_odd", "--dtype", "fp32", "--step", "2", "--schedule", "window", "--stage", "dma", "--xrim", "lds")
+_add("3dodd_fp32_dma_bx128", 3, "t3_odd", "--dtype", "fp32", "--stage", "dma", "--bx", "128", "--by", "2", "--block-merge-y", "2")
+_add("smoke_fp32_dma_s3", 3, "smoke3", "--dtype", "fp32", "--step", "3", "--stage", "dma", "--sn", "12")
+_add("2d25_fp32_dma_stream", 2, "t2_box25", "--dtype", "fp32", "--streaming", "--stage", "dma")
+_add("2d25_fp64_dma_stream_s2", 2, "t2_box25", "--dtype", "fp64", "--streaming", "--step", "2", "--stage", "dma", "--sn", "20")
+_add("2d9s_fp32_dma_stream_d1", 2, "t2_star9", "--dtype", "fp32", "--streaming", "--dist", "1", "--stage", "dma", "--xrim", "lds")
+
 # temporal blocking (on-chip multi-step): equal to the fused stencil up to rounding
 _add("3d7_fp32_t2", 3, "t3_star", "--dtype", "fp32", "--step", "2", "--temporal", "1", "--by", "8", "--block-merge-y", "4", "--sn", "16", "--prefetch")
 _add("3d7_fp64_t2_lds", 3, "t3_star", "--dtype", "fp64", "--step", "2", "--temporal", "1", "--by", "8", "--block-merge-y", "4", "--sn", "9", "--xrim", "lds")
@@ -118,6 +133,9 @@ def _bench_kernels():
 
 _bench_kernels()
 # the reference's legal --dist range on the headline geometry at full size (different kernels, identical results)
+FULL.append(("C4_3d7pt_1024_fp32_fused2_dma", 3, os.path.join(CFG, "c4_3d7pt_star_1024.stc"),
+             ["--3d", "--dtype", "fp32", "--step", "2", "--stage", "dma", "--bx", "32", "--by", "16", "--block-merge-x", "4", "--block-merge-y", "2", "--sn", "32", "--xcd-remap", "2"]))
+FULL.append(("C2_2d5pt_8192_fp32_stream_dma", 2, os.path.join(CFG, "c2_2d5pt_star_8192.stc"), ["--dtype", "fp32", "--streaming", "--stage", "dma"]))
 for _d in ("1", "2"):
     FULL.append(("C4_3d7pt_1024_fp32_fused2_dist%s" % _d, 3, os.path.join(CFG, "c4_3d7pt_star_1024.stc"),
                  ["--3d", "--dtype", "fp32", "--step", "2", "--dist", _d, "--prefetch", "--bx", "32", "--by", "16", "--block-merge-x", "4", "--block-merge-y", "2", "--sn", "32", "--xcd-remap", "2"]))

@@ -74,6 +74,24 @@ VARIANTS = [
     ("2d_tile_buffer_stores", 2, "BOX9", (1, 41, 70), ["--dtype", "fp64", "--store-mask", "buffer"]),
 ]
 
+# --stage dma: planes staged by LDS-DMA into the per-lane-dense LDS image (own region [row][vector][lane], halo pieces by loader task);
+# tile-edge lanes re-read from the halo regions.  Ragged grids: edge tiles, out-of-grid lanes, short blocks; box stencils: corners.
+DMA = [
+    ("3d_dma_s1", 3, "STAR3", (19, 23, 268), ["--3d", "--dtype", "fp32", "--sn", "7", "--stage", "dma"]),
+    ("3d_dma_s2_dpp", 3, "STAR3", (19, 23, 264), ["--3d", "--dtype", "fp32", "--sn", "7", "--step", "2", "--stage", "dma", "--bx", "32", "--by", "4", "--block-merge-y", "2"]),
+    ("3d_dma_s2_lds_fp64", 3, "STAR3", (17, 21, 300), ["--3d", "--dtype", "fp64", "--sn", "6", "--step", "2", "--stage", "dma", "--xrim", "lds", "--bx", "16", "--by", "8", "--block-merge-x", "2", "--block-merge-y", "2"]),
+    ("3d_dma_bx128_wave_edges", 3, "STAR3", (12, 19, 1032), ["--3d", "--dtype", "fp32", "--bx", "128", "--by", "2", "--block-merge-y", "2", "--stage", "dma", "--sn", "5"]),
+    ("3d_dma_cross_s2", 3, "CROSS3", (14, 19, 136), ["--3d", "--dtype", "fp64", "--dist", "2", "--step", "2", "--stage", "dma", "--schedule", "scatter"]),
+    ("3d_dma_reuse_dist1", 3, "STAR3", (19, 23, 264), ["--3d", "--dtype", "fp32", "--sn", "7", "--step", "2", "--dist", "1", "--stage", "dma"]),
+    ("3d_dma_reuse_dist2_mf0", 3, "STAR3", (19, 23, 264), ["--3d", "--dtype", "fp32", "--sn", "4", "--step", "2", "--dist", "2", "--merge-forward", "0", "--stage", "dma", "--xrim", "lds"]),
+    ("3d_dma_window", 3, "STAR3", (19, 23, 264), ["--3d", "--dtype", "fp64", "--sn", "3", "--step", "2", "--schedule", "window", "--stage", "dma"]),
+    ("3d_dma_short_blocks", 3, "STAR3", (9, 11, 140), ["--3d", "--dtype", "fp32", "--sn", "1", "--stage", "dma", "--bx", "16", "--by", "4"]),
+    ("3d_dma_my4", 3, "STAR3", (13, 37, 264), ["--3d", "--dtype", "fp32", "--sn", "5", "--step", "2", "--stage", "dma", "--bx", "32", "--by", "2", "--block-merge-y", "4"]),
+    ("2d_stream_dma_box25", 2, "BOX25", (1, 61, 268), ["--dtype", "fp32", "--streaming", "--sn", "9", "--stage", "dma"]),
+    ("2d_stream_dma_box25_s2_fp64", 2, "BOX25", (1, 61, 268), ["--dtype", "fp64", "--streaming", "--sn", "9", "--step", "2", "--stage", "dma", "--xrim", "lds"]),
+    ("2d_stream_dma_star_dist1", 2, "STAR2", (1, 75, 532), ["--dtype", "fp32", "--streaming", "--step", "2", "--dist", "1", "--sn", "16", "--stage", "dma"]),
+]
+
 # --dist / --merge-forward as real knobs: an explicit --dist selects --schedule reuse -- `Range` source planes in
 # register windows, partial sums carried over the rest -- over the reference's legal range (step-1)*order <= dist <= step*order
 # (benchmarks/3d7pt_star/tuning.py:20), --merge-forward deciding whether a retained plane's neighbours are carried or re-read.
@@ -99,7 +117,7 @@ REUSE = [
 ]
 
 
-@pytest.mark.parametrize("vid,ndim,pts,dims,opts", VARIANTS + REUSE, ids=[v[0] for v in VARIANTS + REUSE])
+@pytest.mark.parametrize("vid,ndim,pts,dims,opts", VARIANTS + REUSE + DMA, ids=[v[0] for v in VARIANTS + REUSE + DMA])
 def test_emulated_variants_bit_exact(vid, ndim, pts, dims, opts, tmp_path):
     mg = _mg()
     stc = str(tmp_path / "v.stc")
@@ -171,6 +189,11 @@ RACE = [
     ("2d_tile_temporal3", 2, "BOX9", (1, 40, 140), ["--dtype", "fp64", "--step", "3", "--temporal", "1", "--xrim", "lds"]),
     ("3d_step2_prefetch_depth2", 3, "STAR3", (23, 21, 300), ["--3d", "--dtype", "fp64", "--sn", "7", "--step", "2", "--prefetch", "--prefetch-depth", "2", "--xrim", "lds"]),
     ("3d_temporal2_prefetch_depth2", 3, "STAR3", (17, 21, 300), ["--3d", "--dtype", "fp64", "--sn", "6", "--step", "2", "--temporal", "1", "--prefetch", "--prefetch-depth", "2", "--xrim", "lds", "--by", "8", "--block-merge-y", "2"]),
+    # LDS-DMA staging: plane n+1 is written into the slot of plane n-1 (or older, with late re-reads) while plane n is read
+    ("3d_dma_scatter", 3, "STAR3", (17, 21, 300), ["--3d", "--dtype", "fp64", "--sn", "6", "--step", "2", "--stage", "dma", "--xrim", "lds"]),
+    ("3d_dma_reuse_late_rereads", 3, "STAR3", (17, 21, 300), ["--3d", "--dtype", "fp64", "--sn", "6", "--step", "2", "--dist", "1", "--merge-forward", "100", "--stage", "dma", "--xrim", "lds"]),
+    ("3d_dma_window_lazy", 3, "STAR3", (15, 19, 300), ["--3d", "--dtype", "fp64", "--sn", "5", "--schedule", "window", "--lazy-rims", "1", "--stage", "dma"]),
+    ("2d_stream_dma", 2, "BOX25", (1, 61, 268), ["--dtype", "fp64", "--streaming", "--sn", "9", "--step", "2", "--stage", "dma"]),
 ]
 
 
@@ -248,6 +271,8 @@ def _emulated_fuzz_jobs(n=14, seed=9):
                     cl += ["--store-mask", "buffer"]
                 if rnd.random() < 0.2:
                     cl += ["--drain", str(rnd.choice([1, 2]))]
+                if rnd.random() < 0.35 and "--temporal" not in cl and "--cyclic-merge-y" not in cl and (ndim == 3 or "--streaming" in cl):
+                    cl += ["--stage", "dma"]          # LDS-DMA staging (16-byte vectors: the generator rejects the others)
                 jobs.append((t.cfgToString(v) + "_" + dtype + "_%dd" % ndim + pts.lower(), ndim, pts, dims, (["--3d"] if ndim == 3 else []) + ["--dtype", dtype] + cl, v[0]))
     return jobs
 
