@@ -60,8 +60,10 @@ TUNED = {
     "c5": ["--dtype", "fp64", "--bx", "64", "--by", "4", "--block-merge-x", "2", "--block-merge-y", "4", "--xcd-remap", "0"],
     # fp64 (profiles/r01_tune_shipped.md: exhaustive searches at the reference sizes): the 2D tile of 2d5pt_star step 1; fused step 2 in 3D
     "c2f64": ["--dtype", "fp64", "--bx", "128", "--by", "4", "--block-merge-x", "2", "--block-merge-y", "2", "--xcd-remap", "0"],
-    "c3f64": ["--3d", "--dtype", "fp64", "--step", "2", "--bx", "128", "--by", "4", "--block-merge-x", "2", "--block-merge-y", "2", "--sn", "32", "--xcd-remap", "2"],
-    "c4f64": ["--3d", "--dtype", "fp64", "--step", "2", "--bx", "128", "--by", "4", "--block-merge-x", "2", "--block-merge-y", "2", "--sn", "32", "--xcd-remap", "2"],
+    # round 2 (profiles/r02_tune_c3f64_s2.txt, the space with the reference's dist dimension): a reuse-schedule kernel wins -- --dist 2 keeps
+    # Range = 3 source planes in register windows and carries two partial sums (669 vs 654 GStencil/s for round 1's 128x4 scatter kernel, same box)
+    "c3f64": ["--3d", "--dtype", "fp64", "--step", "2", "--dist", "2", "--merge-forward", "5", "--prefetch", "--prefetch-depth", "1", "--bx", "32", "--by", "8", "--block-merge-x", "2", "--block-merge-y", "2", "--sn", "64", "--xcd-remap", "2"],
+    "c4f64": ["--3d", "--dtype", "fp64", "--step", "2", "--dist", "2", "--merge-forward", "5", "--prefetch", "--prefetch-depth", "1", "--bx", "32", "--by", "8", "--block-merge-x", "2", "--block-merge-y", "2", "--sn", "64", "--xcd-remap", "2"],
 }
 # the same workloads with one time step per launch: highest roofline fraction.  Full-row tiles (256 lanes x 4
 # points = N), 2 lane rows x 4 rows, 4-plane stream blocks, prefetch: the optimum of the exhaustive 1520-configuration
@@ -212,6 +214,56 @@ def verify_timed_kernel(torch, kern, workload, A, B, step, temporal):
         "ring_untouched": bool(ring_ok), "tolerance": 0.0 if not temporal else tol}, host
 
 
+def _seeded_planes(torch, lo, hi, rest, dtype, device):
+    """Planes [lo, hi) of a grid whose plane z is torch.rand with seed 1000 + z: any rank can produce any plane of the global grid."""
+    out = torch.empty((hi - lo,) + tuple(rest), dtype=dtype, device=device)
+    g = torch.Generator(device=device)
+    for z in range(lo, hi):
+        g.manual_seed(1000 + z)
+        out[z - lo].copy_(torch.rand(tuple(rest), dtype=dtype, device=device, generator=g))
+    return out
+
+
+def slab_verify_view(dim0, H, launches, world, rank):
+    """Global range [lo, hi) of the slab a rank recomputes WITHOUT exchange to check its exchanged run: its own planes plus
+    launches*H planes per interior face (each launch invalidates H more planes from the cut faces inwards)."""
+    from drstencil_amd.multigpu import slab_bounds
+    z0, z1 = slab_bounds(dim0, world, rank)
+    return max(0, z0 - launches * H), min(dim0, z1 + launches * H)
+
+
+def verify_slab_run(torch, dist, run, sweep, dims, H, launches, iters, rank, world, dev, tdt):
+    """N > 1: is the decomposed run (slab views, boundary / interior / pair kernels, RCCL halo exchange over xGMI) the
+    single-domain run?  Every rank fills its slab with seeded planes of the GLOBAL grid, runs the reference's loop through
+    SlabRun (with exchange), then recomputes the same launches on a wider slab of the same global grid with plain launches
+    and NO exchange -- wide enough that its own planes cannot be reached by the missing neighbours -- and compares its own
+    planes bit for bit.  No rank needs another rank's result; the verdicts are AND-ed over the ranks."""
+    gpu = dev.type == "cuda"          # (the gloo test runs this on CPU tensors with the oracle as the sweep)
+    sync = torch.cuda.synchronize if gpu else (lambda: None)
+    p = run.plan
+    rest = tuple(dims[1:])
+    run.A.copy_(_seeded_planes(torch, p.lo, p.hi, rest, tdt, dev))
+    run.B.zero_()
+    sync()
+    dist.barrier()
+    n = run.run(iterations=iters)
+    sync()
+    lo, hi = slab_verify_view(dims[0], H, launches, world, rank)
+    A = _seeded_planes(torch, lo, hi, rest, tdt, dev)
+    B = torch.zeros_like(A)
+    stream = torch.cuda.current_stream(dev).cuda_stream if gpu else 0
+    for _ in range(n // 2):
+        sweep(A, B, stream)
+        sweep(B, A, stream)
+    sync()
+    okA = torch.equal(run.owned(run.A), A[p.z0 - lo:p.z1 - lo])
+    okB = torch.equal(run.owned(run.B), B[p.z0 - lo:p.z1 - lo])
+    flag = torch.tensor([1 if (okA and okB) else 0], dtype=torch.int32, device=dev)
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    return bool(int(flag[0])), {"decomposed_vs_single_domain": {"ok": bool(int(flag[0])), "this_rank_ok": bool(okA and okB), "launches": n, "bit_exact_required": True,
+                                                                "how": "own planes of the exchanged run == plain launches on [z0 - %d, z1 + %d) of the same seeded global grid" % (launches * H, launches * H)}}
+
+
 def device_info(torch, dev):
     """Which MI355X this was (boxes differ by a few per cent in memory clocks): name, uuid, CU count -- from the HIP device
     properties, no child process."""
@@ -353,6 +405,9 @@ def main(argv=None):
         for r in (range(pworld) if args.prebuild_only else (prank,)):
             for ev in ((1, 2) if auto_every else (args.exchange_every,)):      # both modes' kernels: built (cache hits) before HIP is up
                 sweep.prebuild(SlabPlan(L if w["ndim"] == 3 else M, H, pworld, r, ev))
+            if not args.no_verify and not rehearse:       # the wider no-exchange slab of verify_slab_run
+                vlo, vhi = slab_verify_view(L if w["ndim"] == 3 else M, H, spec.launches, pworld, r)
+                sweep.kernel(vhi - vlo)
     if args.prebuild_only:
         print("bench.py: kernels for %d rank(s) of %s are in the cache" % (pworld, args.workload), file=sys.stderr)
         return
@@ -467,6 +522,8 @@ def main(argv=None):
         parallelism = "%s-slab x%d%s, RCCL send/recv halo every %d launch(es), overlapped" % ("z" if w["ndim"] == 3 else "y", pworld, " (weak: grid %s)" % "x".join(str(d) for d in ((L, M, N) if w["ndim"] == 3 else (M, N))) if weak else "", args.exchange_every)
         step1 = fused2 = None
         verified, verification, host_slab = None, None, None     # the slab kernels' parity is tests/test_gpu_parity.py::test_c4_slab_views_at_full_size
+        if not args.no_verify and not rehearse:      # (a rehearsal's self-neighbour exchange is not the physical one)
+            verified, verification = verify_slab_run(torch, dist, run, sweep, (L, M, N) if w["ndim"] == 3 else (M, N), H, launches_per_step, iters, prank, pworld, dev, tdt)
 
     if rank == 0:
         total_launches = launches_per_step * args.steps

@@ -205,12 +205,13 @@ def enumerate_space(steps=(1,), full=False):
 
 # ---- register model -----------------------------------------------------------------------------------------------
 # P(the kernel spills to scratch and is refused by the runtime) from what the generator knows before compiling: a logistic
-# model fitted to hipcc's resource reports of 550 random configurations of the 3D / 2D spaces (scripts/fit_reg_model.py ->
-# profiles/r02_reg_model.md).  Dropping configurations with P > 0.6 leaves 9.6 % of the compiled ones refused (28 % without
-# the filter; round 1: 45 % of the random 3D ones) for 4.3 % of the usable ones lost.
-SPILL_BIAS = -5.8552
-SPILL_W = [9.5442, -0.5771, -1.4978, 0.2913, -15.0436]
-SPILL_THRESHOLD = 0.6
+# model fitted to 1 363 labelled configurations -- hipcc's resource reports of 550 random configurations of the 3D / 2D spaces
+# plus the outcomes of a tuner run on C4 step 2 (scripts/fit_reg_model.py -> profiles/r02_reg_model.md).  Dropping
+# configurations with P > 0.35 leaves ~2 % of the compiled ones refused (23 % without the filter; round 1: 45 % of the random
+# 3D ones) for ~4 % of the usable ones lost; on a 30 % holdout: 2.3 % / 4.5 %.
+SPILL_BIAS = -10.9634
+SPILL_W = [23.8021, 0.4993, -4.569, -0.4493, -79.6849, -0.3832, -9.2073, -0.0079, 6.8813, -3.2165, 4.6751, -6.2845]
+SPILL_THRESHOLD = 0.35
 
 
 def lane_register_budget(threads):
@@ -219,17 +220,31 @@ def lane_register_budget(threads):
     return 512 // max(1, waves_per_simd) // 8 * 8
 
 
-def spill_features(demand, threads, taps, pts, stages, words):
+def spill_features(demand, threads, taps, pts, stages, words, schedule="scatter", depth=0):
+    """x1 demand / budget, x2 FMAs per plane / budget, temporal, fp64, points / budget, <= 256 lanes (AGPR half usable), reuse
+    schedule, prefetch depth / 3, and four interactions of x1."""
     b = float(lane_register_budget(threads))
-    return [demand / b, words * taps * pts * stages / b, 1.0 if stages > 1 else 0.0, words - 1.0, words * pts / b]
+    x1 = demand / b
+    x2 = words * taps * pts * stages / b
+    tmp = 1.0 if stages > 1 else 0.0
+    small = 1.0 if threads <= 256 else 0.0
+    return [x1, x2, tmp, words - 1.0, words * pts / b, small, 1.0 if schedule == "reuse" else 0.0, depth / 3.0, x1 * x1, x1 * x2, x1 * small, x1 * tmp]
 
 
-def spill_probability(info):
-    """info = the generator's kernel info (drs_plugin_info JSON of the emitted source)."""
+def prefetch_depth_of(args):
+    args = list(args)
+    if "--prefetch-depth" in args:
+        return int(args[args.index("--prefetch-depth") + 1])
+    return 1 if "--prefetch" in args else 0
+
+
+def spill_probability(info, depth=0):
+    """info = the generator's kernel info (drs_plugin_info JSON of the emitted source); depth = planes of software prefetch."""
     import math
-    x = spill_features(info["reg_demand"], info["threads"], info["taps"], info["points_per_lane"], info["stages"], 1 if info["dtype"] == "fp32" else 2)
+    x = spill_features(info["reg_demand"], info["threads"], info["taps"], info["points_per_lane"], info["stages"], 1 if info["dtype"] == "fp32" else 2,
+                       info.get("schedule", "scatter"), depth)
     z = SPILL_BIAS + sum(w * v for w, v in zip(SPILL_W, x))
-    return 1.0 / (1.0 + math.exp(-z))
+    return 1.0 / (1.0 + math.exp(-max(-60.0, min(60.0, z))))
 
 
 def kernel_info(args):
@@ -248,7 +263,7 @@ def registerFilter(args):
     info = kernel_info(args)
     if info is None:
         return True            # let the build report the generator's own error
-    return spill_probability(info) <= SPILL_THRESHOLD
+    return spill_probability(info, prefetch_depth_of(args)) <= SPILL_THRESHOLD
 
 
 def getElapsedTime(start, end):
@@ -452,6 +467,7 @@ def main():
     ap.add_argument("--configs-file", default=None, help="file with one raw option string per line instead of the space")
     ap.add_argument("--profile-top", type=int, default=0, help="after the search: rocprofv3 counters of the best N configurations -> <out>/gpuMetrics.csv (reference flow)")
     ap.add_argument("--jobs", type=int, default=16, help="compile workers")
+    ap.add_argument("--extra", default="", help="generator options added to every configuration (e.g. \"--cc-opt -fno-slp-vectorize\")")
     a = ap.parse_args()
     order, ndim, elem_bytes = a.order, (3 if a.is3d else 2), (4 if a.dtype == "fp32" else 8)
     if a.configs_file:
@@ -467,7 +483,8 @@ def main():
         for p in paras[:5]:
             print(cfgToString(p) if not isinstance(p, str) else p, "|", cfgToCommandLine(p) if not isinstance(p, str) else "")
         return
-    res = searchSpace(os.path.abspath(a.stc), a.is3d, a.dtype, paras, a.out, budget_s=a.budget or None, jobs=a.jobs, profile_top=a.profile_top)
+    res = searchSpace(os.path.abspath(a.stc), a.is3d, a.dtype, paras, a.out, budget_s=a.budget or None, jobs=a.jobs, profile_top=a.profile_top,
+                      extra_opts=a.extra.split())
     print("best:")
     for r in res[:10]:
         print("  {name}  {duration_ns:.0f} ns  {GBps:.0f} GB/s  {GStencil:.1f} GStencil/s".format(**r))

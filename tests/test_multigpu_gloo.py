@@ -166,3 +166,53 @@ def test_2d_y_slab_decomposition_matches_single_domain(every):
     for rank, n, z0, z1, a, b in parts:
         assert n == n_ref
         assert np.array_equal(a, A[z0:z1]) and np.array_equal(b, B[z0:z1])
+
+
+def _verify_worker(rank, world, port, step, iterations, every, break_exchange, q):
+    sys.path.insert(0, ROOT)
+    import bench
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    spec = oracle.Spec(STC, 3, step)
+    L, M, N = spec.dims
+    H = spec.halo
+
+    def sweep(src, dst, stream):
+        vs = oracle.Spec(STC, 3, step)
+        vs.set_dims(src.shape[0], M, N)
+        oracle.sweep(vs, src.numpy(), dst.numpy(), 1)
+
+    run = SlabRun(torch, dist, (L, M, N), H, step, iterations, rank, world, sweep, torch.device("cpu"), torch.float32, every=every)
+    if break_exchange and rank == 1:
+        real = run._exchange
+
+        def stale(dst):           # a rank whose received ghost planes are wrong: the check must say so on every rank
+            real(dst)
+            if run.plan.has_up:
+                dst[run.plan.recv_up[0]:run.plan.recv_up[1]].zero_()
+        run._exchange = stale
+    ok, detail = bench.verify_slab_run(torch, dist, run, sweep, (L, M, N), H, spec.launches, iterations, rank, world, torch.device("cpu"), torch.float32)
+    q.put((rank, ok, detail["decomposed_vs_single_domain"]["this_rank_ok"]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,step,every,break_exchange", [(2, 2, 1, False), (3, 1, 2, False), (2, 2, 1, True)])
+def test_bench_verifies_a_decomposed_run_without_a_global_reference(world, step, every, break_exchange):
+    """bench.py's N > 1 check (verify_slab_run): each rank compares its exchanged run with plain launches on a wider slab of the
+    same seeded global grid -- green for a correct exchange, red on EVERY rank when one rank's ghost planes are stale."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_verify_worker, args=(r, world, port, step, 4, every, break_exchange, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=180) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+    assert [r[0] for r in res] == list(range(world))
+    if break_exchange:
+        assert not any(r[1] for r in res) and not res[1][2]        # AND over the ranks; rank 1 itself saw the difference
+    else:
+        assert all(r[1] and r[2] for r in res)
