@@ -60,10 +60,11 @@ TUNED = {
     "c5": ["--dtype", "fp64", "--bx", "64", "--by", "4", "--block-merge-x", "2", "--block-merge-y", "4", "--xcd-remap", "0"],
     # fp64 (profiles/r01_tune_shipped.md: exhaustive searches at the reference sizes): the 2D tile of 2d5pt_star step 1; fused step 2 in 3D
     "c2f64": ["--dtype", "fp64", "--bx", "128", "--by", "4", "--block-merge-x", "2", "--block-merge-y", "2", "--xcd-remap", "0"],
-    # round 2 (profiles/r02_tune_c3f64_s2.txt, the space with the reference's dist dimension): a reuse-schedule kernel wins -- --dist 2 keeps
-    # Range = 3 source planes in register windows and carries two partial sums (669 vs 654 GStencil/s for round 1's 128x4 scatter kernel, same box)
-    "c3f64": ["--3d", "--dtype", "fp64", "--step", "2", "--dist", "2", "--merge-forward", "5", "--prefetch", "--prefetch-depth", "1", "--bx", "32", "--by", "8", "--block-merge-x", "2", "--block-merge-y", "2", "--sn", "64", "--xcd-remap", "2"],
-    "c4f64": ["--3d", "--dtype", "fp64", "--step", "2", "--dist", "2", "--merge-forward", "5", "--prefetch", "--prefetch-depth", "1", "--bx", "32", "--by", "8", "--block-merge-x", "2", "--block-merge-y", "2", "--sn", "64", "--xcd-remap", "2"],
+    # round 2: a tuner run over the space with the reference's dist dimension put a reuse-schedule kernel (32x8 lanes, --dist 2) 2 % ahead on
+    # its box (profiles/r02_tune_c3f64_s2.txt); the interleaved comparison on another box has round 1's scatter kernel 4-5 % ahead at both sizes
+    # (profiles/r02_exp_r2i_diagnostics.log: 0.374 vs 0.388 ms at 512^3, 3.04 vs 3.22 ms at 1024^3), so it stays, with -fno-slp-vectorize (+0.3 %)
+    "c3f64": ["--3d", "--dtype", "fp64", "--step", "2", "--bx", "128", "--by", "4", "--block-merge-x", "2", "--block-merge-y", "2", "--sn", "32", "--xcd-remap", "2", "--cc-opt", "-fno-slp-vectorize"],
+    "c4f64": ["--3d", "--dtype", "fp64", "--step", "2", "--bx", "128", "--by", "4", "--block-merge-x", "2", "--block-merge-y", "2", "--sn", "32", "--xcd-remap", "2", "--cc-opt", "-fno-slp-vectorize"],
 }
 # the same workloads with one time step per launch: highest roofline fraction.  Full-row tiles (256 lanes x 4
 # points = N), 2 lane rows x 4 rows, 4-plane stream blocks, prefetch: the optimum of the exhaustive 1520-configuration
@@ -77,6 +78,13 @@ STEP1 = {
 TEMPORAL2 = {
     "c4": ["--3d", "--dtype", "fp32", "--step", "2", "--temporal", "1", "--prefetch", "--bx", "66", "--by", "15", "--block-merge-x", "4", "--block-merge-y", "2", "--sn", "32", "--xcd-remap", "0"],
     "c3": ["--3d", "--dtype", "fp32", "--step", "2", "--temporal", "1", "--prefetch", "--bx", "66", "--by", "15", "--block-merge-x", "4", "--block-merge-y", "2", "--sn", "16", "--xcd-remap", "0"],
+}
+# round 2: the same fused stencil with rotating register windows instead of carried partial sums (--schedule window): 126 VGPRs with
+# -fno-slp-vectorize and --waves-per-eu 4, no scratch, so TWO 512-lane workgroups share a CU (one reads while the other writes) and 8-plane
+# stream blocks cost nothing: +0.8 % over the headline in interleaved runs on one box (profiles/r02_exp_r2j/k_*.log) -- a side measurement
+WINDOW2WG = {
+    "c4": ["--3d", "--dtype", "fp32", "--step", "2", "--schedule", "window", "--prefetch", "--prefetch-depth", "1", "--waves-per-eu", "4", "--bx", "32", "--by", "16",
+           "--block-merge-x", "4", "--block-merge-y", "2", "--sn", "8", "--xcd-remap", "2", "--cc-opt", "-fno-slp-vectorize"],
 }
 # N > 1 (z slabs of C4): the same fused kernel; slabs of 256 planes or fewer get 16-plane stream blocks.  One stream block
 # per tile (256 tiles = one workgroup per CU) is the fastest way to sweep a slab ALONE (128-plane view 0.186 ms vs 0.199,
@@ -100,6 +108,7 @@ def kernels():
     out = [("bench_%s_headline" % w, w, TUNED[w]) for w in sorted(TUNED)]
     out += [("bench_%s_step1" % w, w, STEP1[w]) for w in sorted(STEP1)]
     out += [("bench_%s_temporal2" % w, w, TEMPORAL2[w]) for w in sorted(TEMPORAL2)]
+    out += [("bench_%s_window_two_workgroups" % w, w, WINDOW2WG[w]) for w in sorted(WINDOW2WG)]
     return out
 
 
@@ -392,12 +401,17 @@ def main(argv=None):
             L *= pworld
         else:
             M *= pworld
-    kern1 = kernf = None
+    kern1 = kernf = kernw = None
     if pworld == 1:
         kern = drs.Kernel(opts + [w["stc"]])
         if args.workload in STEP1 and not args.kernel_args and not args.headline_only:
             kern1 = drs.Kernel(STEP1[args.workload] + [w["stc"]])
             kernf = drs.Kernel(TEMPORAL2[args.workload] + [w["stc"]])
+            if args.workload in WINDOW2WG:
+                try:
+                    kernw = drs.Kernel(WINDOW2WG[args.workload] + [w["stc"]])
+                except drs.KernelBuildError:          # a compiler that does not reach 126 registers without scratch: no side measurement
+                    kernw = None
     else:
         from drstencil_amd.multigpu import HipSweep, SelfNeighbourRun, SlabPlan, SlabRun, measure_exchange_every
         auto_every = args.exchange_every == 0      # decided after the process group is up, from measured sweep / exchange times
@@ -475,6 +489,7 @@ def main(argv=None):
                     "roofline_frac": by * n1 / (ms1 * 1e-3) / 1e9 / HBM_PEAK_GBS}
         step1 = side(kern1, STEP1[args.workload], 16) if kern1 is not None else None
         fused2 = side(kernf, TEMPORAL2[args.workload], 32) if kernf is not None else None
+        window2 = side(kernw, WINDOW2WG[args.workload], 32) if kernw is not None else None
         verified, verification, host_slab = None, None, None
         if not args.no_verify:
             g = torch.Generator(device=dev).manual_seed(1)
@@ -520,7 +535,7 @@ def main(argv=None):
         kinfo = sweep.kernel(run.plan.interior[1] - run.plan.interior[0]).info
         kres = sweep.kernel(run.plan.interior[1] - run.plan.interior[0]).resources
         parallelism = "%s-slab x%d%s, RCCL send/recv halo every %d launch(es), overlapped" % ("z" if w["ndim"] == 3 else "y", pworld, " (weak: grid %s)" % "x".join(str(d) for d in ((L, M, N) if w["ndim"] == 3 else (M, N))) if weak else "", args.exchange_every)
-        step1 = fused2 = None
+        step1 = fused2 = window2 = None
         verified, verification, host_slab = None, None, None     # the slab kernels' parity is tests/test_gpu_parity.py::test_c4_slab_views_at_full_size
         if not args.no_verify and not rehearse:      # (a rehearsal's self-neighbour exchange is not the physical one)
             verified, verification = verify_slab_run(torch, dist, run, sweep, (L, M, N) if w["ndim"] == 3 else (M, N), H, launches_per_step, iters, prank, pworld, dev, tdt)
@@ -562,6 +577,7 @@ def main(argv=None):
             out["config"]["exchange_calibration"] = calibration      # measured on this machine during warm-up (multigpu.measure_exchange_every)
         out["step1_kernel"] = step1                 # one time step per launch: highest roofline fraction
         out["temporal_step2_kernel"] = fused2       # on-chip temporal blocking (2 stages): equal to the headline up to rounding
+        out["two_workgroups_per_cu_kernel"] = window2   # the same fused arithmetic from rotating register windows at 126 VGPRs: two workgroups per CU
         if not args.no_cpu_baseline and pworld == 1:
             sys.path.insert(0, ROOT)
             out["cpu_baseline"] = cpu_baseline(args.workload, step, host_slab=host_slab)

@@ -312,9 +312,9 @@ drs_kernel *drs_kernel_build(int argc, const char *const *argv, const char *cach
         return nullptr;
     }
     // kernels with barriers removed (--debug-drop-barrier: timing experiments, wrong results) load only when asked for
-    if (r.opt.debug_drop_barrier) {
+    if (r.opt.debug_drop_barrier || r.opt.debug_skip) {
         const char *ex = getenv("DRS_EXPERIMENTS");
-        if (!(ex && ex[0] == '1')) { if (log) *log = dup_cstr("drstencil: --debug-drop-barrier kernels compute wrong results; they load only with DRS_EXPERIMENTS=1\n"); return nullptr; }
+        if (!(ex && ex[0] == '1')) { if (log) *log = dup_cstr("drstencil: --debug-drop-barrier / --debug-skip kernels compute wrong results; they load only with DRS_EXPERIMENTS=1\n"); return nullptr; }
     }
     void *dl = dlopen(so.c_str(), RTLD_NOW | RTLD_LOCAL);
     if (!dl) { if (log) *log = dup_cstr(std::string("dlopen failed: ") + dlerror() + "\n"); return nullptr; }

@@ -98,6 +98,8 @@ MI355X options:
 --stage <reg|dma>       How an arriving plane reaches LDS in streaming kernels: reg (default) = global loads into VGPRs
                         (software prefetch) + LDS writes; dma = LDS-DMA (global_load_lds_dwordx4) straight into the plane's
                         LDS slot, one plane ahead, no prefetch registers (16-byte vectors, block y merging, one stage).
+--defer-stores <0|1>    Hold a completed output plane in registers and store it one plane later, right after the next
+                        plane's loads were issued (its write latency runs under that plane's work).
 --drain <0|1|2>         s_waitcnt vmcnt(0) before every plane's prefetch loads (1) or before its LDS staging (2).
 --cc-opt <flag>         Extra hipcc flag for this kernel (repeatable), e.g. --cc-opt -fno-slp-vectorize.
 --clamp-loads <0|1>     1 (default): branch-free loads -- lanes outside the grid read the plane origin (their
@@ -161,6 +163,7 @@ inline GenResult generate(const std::vector<std::string> &args /* argv[1..] */) 
         else if (a == "--schedule") { if (!str_opt(o.schedule)) break; o.schedule_set = true; }
         else if (a == "--exact-y") { if (!int_opt(o.exact_y, nullptr)) break; }
         else if (a == "--xedge-select") { if (!int_opt(o.xedge_select, nullptr)) break; }
+        else if (a == "--debug-skip") { if (!int_opt(o.debug_skip, nullptr)) break; }
         else if (a == "--debug-drop-barrier") { if (!int_opt(o.debug_drop_barrier, nullptr)) break; }
         else if (a == "--clamp-loads") { if (!int_opt(o.clamp_loads, nullptr)) break; }
         else if (a == "--halo-spread") { if (!int_opt(o.halo_spread, nullptr)) break; }
@@ -169,6 +172,7 @@ inline GenResult generate(const std::vector<std::string> &args /* argv[1..] */) 
         else if (a == "--prefetch-auto") { if (!int_opt(o.prefetch_auto, nullptr)) break; }
         else if (a == "--prefetch-depth") { if (!int_opt(o.prefetch_depth, nullptr)) break; }
         else if (a == "--temporal") { if (!int_opt(o.temporal, nullptr)) break; }
+        else if (a == "--defer-stores") { if (!int_opt(o.defer_stores, nullptr)) break; }
         else if (a == "--drain") { if (!int_opt(o.drain, nullptr)) break; }
         else if (a == "--uniform-loads") { if (!int_opt(o.uniform_loads, nullptr)) break; }
         else if (a == "--store-mask") { if (!str_opt(o.store_mask)) break; }

@@ -65,6 +65,11 @@ struct GenOptions {
     int exact_y = -1;            // 1: halo loaders also fetch the source plane's y halo rows (every tile row owned);
                                  // 0: overlapped tiles; -1 auto: 1 for single-stage kernels, 0 for temporal pipelines
                                  // (measured: +3 % at step 1, -12 % on the 2-stage pipeline whose lanes own only 2 rows)
+    int debug_skip = 0;          // TIMING EXPERIMENTS ONLY (results are wrong; such kernels load only with DRS_EXPERIMENTS=1), a bit mask of what the
+                                 // kernel leaves out so that the parts of a plane iteration can be timed separately: 1 the x-halo loader tasks,
+                                 // 2 the y-halo loader tasks, 4 every tap that is not on the lane's own point (5 of 25 FMAs left for the fused
+                                 // 7-point star, no rim reads), 8 every store except the block's last plane (the sums become dead code: what
+                                 // remains is loads + LDS staging + barrier)
     int debug_drop_barrier = 0;  // TIMING EXPERIMENTS ONLY: 1 drops the barriers of stages >= 1, 2 also the per-plane barrier of single-stage kernels (results are wrong)
     int clamp_loads = 1;         // branch-free loads (out-of-grid lanes read the plane origin) and uniform-guarded scalar stores
     int halo_spread = 0;         // spread the halo loader tasks over all wavefronts of the workgroup (no gain measured)
@@ -82,6 +87,9 @@ struct GenOptions {
     // stores the compiler cannot count the vector-memory operations in flight and drains them (s_waitcnt vmcnt(0)) every plane;
     // an exactly counted pipeline (uniform loads + buffer-masked stores) keeps 3-4 planes in flight and is 1-10 % SLOWER, because
     // buffer stores cost 6 % (50 % where a quarter of the lanes is masked) and the per-plane drain itself is worth 3 %.
+    int defer_stores = 0;        // 1: a completed output plane is held in registers (points-per-lane VGPRs) and stored one iteration later, right
+                                 // after the next plane's loads have been issued: its write latency runs under that iteration's exchange and
+                                 // FMAs instead of sitting in front of the per-plane drain (single-stage streaming kernels)
     int drain = 0;               // 1: s_waitcnt vmcnt(0) before the prefetch loads of every plane are issued (a workgroup's reads and writes
                                  // never overlap); 2: at the top of the iteration, before the staged plane is written to LDS; 0: none
     int uniform_loads = 0;       // --prefetch: 0: plane loads under `if (the block still needs planes)`; 1: issued unconditionally (past the

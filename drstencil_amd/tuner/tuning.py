@@ -113,41 +113,49 @@ def FilterParams(spaceVector):
     return True
 
 
+class Cfg:
+    """A space vector with names.  The reference addresses its vector by position (benchmarks/3d7pt_star/tuning.py:38,58); here
+    one record feeds both renderings below, so the option list and the name scheme cannot drift apart."""
+    FIELDS = ("step", "dist", "block", "sn", "unroll", "block_x", "mx", "block_y", "my", "merge_forward", "prefetch", "xrim", "temporal", "xcd", "streaming", "schedule")
+
+    def __init__(self, spaceVector):
+        for k, v in zip(self.FIELDS, _unpack(spaceVector)):
+            setattr(self, k, v)
+        self.bx, self.by = self.block
+        self.depth = int(self.prefetch)          # planes of software prefetch in flight (True == 1, 0 = off)
+
+
+# One row per piece of a configuration: (generator option(s), name fragment, value(s) taken from a Cfg, emitted when).
+# The first seven rows ARE the reference's scheme -- its option order (tuning.py:39-54) and its name fragments
+# (fu<step>d<dist>bx<bx>y<by>sn<sn>u<unroll>[bc]mx<n>[bc]my<n>mf<t>[p], tuning.py:59-74) -- so logs stay comparable; the rest are
+# the MI355X additions (prefetch depth, x-rim path, tile order, temporal blocking, 2D streaming, reuse schedule).
+_PIECES = [
+    ("--bx {0} --by {1} --sn {2} --stream-unroll {3}", "bx{0}y{1}sn{2}u{3}", lambda c: (c.bx, c.by, c.sn, c.unroll), lambda c: True),
+    ("--step {0} --dist {1}",                          "fu{0}d{1}",          lambda c: (c.step, c.dist),             lambda c: True),
+    ("--block-merge-x {0}",                            "bmx{0}",             lambda c: (c.mx,),                      lambda c: c.block_x),
+    ("--cyclic-merge-x {0}",                           "cmx{0}",             lambda c: (c.mx,),                      lambda c: not c.block_x),
+    ("--block-merge-y {0}",                            "bmy{0}",             lambda c: (c.my,),                      lambda c: c.block_y),
+    ("--cyclic-merge-y {0}",                           "cmy{0}",             lambda c: (c.my,),                      lambda c: not c.block_y),
+    ("--merge-forward {0}",                            "mf{0}",              lambda c: (c.merge_forward,),           lambda c: True),
+    ("--prefetch --prefetch-depth {0}",                "p{1}",               lambda c: (c.depth, "" if c.depth == 1 else c.depth), lambda c: c.depth > 0),
+    ("--xrim {0} --xcd-remap {1}",                     "x{2}m{1}",           lambda c: (c.xrim, c.xcd, c.xrim[0]),   lambda c: True),
+    ("--temporal 1",                                   "t",                  lambda c: (),                           lambda c: c.temporal),
+    ("--streaming",                                    "s",                  lambda c: (),                           lambda c: c.streaming),
+    # --dist is always on the command line (reference scheme) and alone selects the reuse schedule: scatter is spelled out
+    ("--schedule scatter",                             "",                   lambda c: (),                           lambda c: c.schedule == "scatter"),
+    ("",                                               "r",                  lambda c: (),                           lambda c: c.schedule == "reuse"),
+]
+_NAME_ORDER = (1, 0) + tuple(range(2, len(_PIECES)))      # the name leads with fu<step>d<dist>, the command line with the block shape
+
+
 def cfgToCommandLine(spaceVector):
-    step, dist, blockSize, sn, s_unroll, blockMergeX, mergeFactorX, blockMergeY, mergeFactorY, m_threshold, prefetch, xrim, temporal, xcd, streaming, schedule = _unpack(spaceVector)
-    cmd = " --bx {0} --by {1} --sn {2} --stream-unroll {3}".format(blockSize[0], blockSize[1], sn, s_unroll)
-    cmd += " --step {0} --dist {1}".format(step, dist)
-    if blockMergeX:
-        cmd += " --block-merge-x {0}".format(mergeFactorX)
-    else:
-        cmd += " --cyclic-merge-x {0}".format(mergeFactorX)
-    if blockMergeY:
-        cmd += " --block-merge-y {0}".format(mergeFactorY)
-    else:
-        cmd += " --cyclic-merge-y {0}".format(mergeFactorY)
-    cmd += " --merge-forward {0}".format(m_threshold)
-    if prefetch:
-        cmd += " --prefetch --prefetch-depth {0}".format(int(prefetch))   # planes in flight (True == 1)
-    cmd += " --xrim {0} --xcd-remap {1}".format(xrim, xcd)
-    if temporal:
-        cmd += " --temporal 1"
-    if streaming:
-        cmd += " --streaming"
-    if schedule == "scatter":
-        cmd += " --schedule scatter"     # --dist is always on the command line (reference scheme) and alone would select reuse
-    return cmd
+    c = Cfg(spaceVector)
+    return "".join(" " + opt.format(*val(c)) for opt, _n, val, when in _PIECES if opt and when(c))
 
 
 def cfgToString(spaceVector):
-    step, dist, blockSize, sn, s_unroll, blockMergeX, mergeFactorX, blockMergeY, mergeFactorY, m_threshold, prefetch, xrim, temporal, xcd, streaming, schedule = _unpack(spaceVector)
-    cmd = "fu{0}d{1}bx{2}y{3}sn{4}u{5}".format(step, dist, blockSize[0], blockSize[1], sn, s_unroll)
-    cmd += ("bmx{0}" if blockMergeX else "cmx{0}").format(mergeFactorX)
-    cmd += ("bmy{0}" if blockMergeY else "cmy{0}").format(mergeFactorY)
-    cmd += "mf{0}".format(m_threshold)
-    if prefetch:
-        cmd += "p" if int(prefetch) == 1 else "p{0}".format(int(prefetch))
-    cmd += "x" + xrim[0] + "m" + str(xcd) + ("t" if temporal else "") + ("s" if streaming else "") + ("r" if schedule == "reuse" else "")
-    return cmd
+    c = Cfg(spaceVector)
+    return "".join(_PIECES[i][1].format(*_PIECES[i][2](c)) for i in _NAME_ORDER if _PIECES[i][3](c))
 
 
 def enumerate_space(steps=(1,), full=False):
@@ -267,7 +275,8 @@ def registerFilter(args):
 
 
 def getElapsedTime(start, end):
-    return (end - start).seconds + (end - start).microseconds / 1e6
+    """Seconds between two datetimes (the reference's helper of the same name, tuning.py:77)."""
+    return (end - start).total_seconds()
 
 
 def measure(kern, torch, A, B, iterations, warmup=10):

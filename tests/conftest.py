@@ -200,6 +200,8 @@ def pytest_sessionstart(session):
         for r in range(world):
             for every in (1, 2):
                 sw.prebuild(SlabPlan(cut, spec.halo, world, r, every))
+    # the one-rank world of test_rccl_exchange_choreography_on_one_gpu's bench.verify_slab_run call: the whole-grid view
+    HipSweep(stcp("t3_star"), ["--3d", "--dtype", "fp32", "--step", "2", "--sn", "16"], SLAB_CACHE).kernel(drs.Spec(stcp("t3_star"), 3, 2).dims[0])
     # ... and of test_c4_slab_views_at_full_size: what bench.py --gpus 2/4/8 launches
     import bench
     from gpu_cases import C4_SLAB_WORLDS

@@ -50,6 +50,19 @@ def main():
                     i = cl.index("--dist"); cl[i + 1] = str(2 * v[0])
                 if "--prefetch-depth" in cl:
                     cl[cl.index("--prefetch-depth") + 1] = str(random.choice([1, 2, 3]))
+                # round-2 knobs: --merge-forward of the reuse schedule, the memory path, LDS-DMA staging
+                if "--schedule" not in cl and random.random() < 0.6:
+                    cl[cl.index("--merge-forward") + 1] = str(random.choice([0, 2, 3, 100]))
+                if random.random() < 0.25:
+                    cl += ["--uniform-loads", str(random.choice([1, 2]))]
+                if random.random() < 0.25:
+                    cl += ["--store-mask", "buffer"]
+                if random.random() < 0.15:
+                    cl += ["--drain", str(random.choice([1, 2]))]
+                if random.random() < 0.3 and "--temporal" not in cl and "--cyclic-merge-y" not in cl and (ndim == 3 or "--streaming" in cl):
+                    cl += ["--stage", "dma"]
+                if random.random() < 0.3:
+                    cl += ["--defer-stores", "1"]
                 jobs.append((ndim, dtype, (["--3d"] if ndim == 3 else []) + ["--dtype", dtype] + cl + [stc], dims))
     t0 = time.time()
     with ProcessPoolExecutor(max_workers=16) as ex:
@@ -61,7 +74,9 @@ def main():
     import torch
     bad = exact = 0
     worst = {"fp32": 0.0, "fp64": 0.0}
-    for (ndim, dtype, args, dims), k in kerns:
+    for cnt, ((ndim, dtype, args, dims), k) in enumerate(kerns, 1):
+        if cnt % 50 == 0:
+            print("... %d / %d checked, %d mismatches" % (cnt, len(kerns), bad), flush=True)      # a long silent run looks hung to the GPU pool
         tdt = torch.float32 if dtype == "fp32" else torch.float64
         shape = dims if ndim == 3 else dims[1:]
         g = torch.Generator(device="cuda").manual_seed(7)

@@ -49,6 +49,8 @@ def make_jobs(n, seed):
                     cl += ["--drain", str(random.choice([1, 2]))]
                 if random.random() < 0.3 and "--temporal" not in cl and "--cyclic-merge-y" not in cl and (ndim == 3 or "--streaming" in cl):
                     cl += ["--stage", "dma"]
+                if random.random() < 0.3:
+                    cl += ["--defer-stores", "1"]
                 args = (["--3d"] if ndim == 3 else []) + ["--dtype", dtype] + cl + [stc]
                 jobs.append((ndim, stc, dtype, args, v[0]))
     return jobs
@@ -91,7 +93,9 @@ def main():
     bad = 0
     worst = {"fp32": 0.0, "fp64": 0.0}
     exact = 0
-    for job, k in kerns:
+    for cnt, (job, k) in enumerate(kerns, 1):
+        if cnt % 100 == 0:
+            print("... %d / %d checked, %d mismatches" % (cnt, len(kerns), bad), flush=True)
         good, temporal, rel = check(job, k, torch)
         if temporal:
             worst[job[2]] = max(worst[job[2]], rel)

@@ -72,6 +72,13 @@ VARIANTS = [
     ("2d_tile_branch_stores", 2, "BOX9", (1, 41, 70), ["--dtype", "fp64", "--store-mask", "branch"]),
     ("3d_buffer_stores_uniform_loads", 3, "STAR3", (19, 23, 262), ["--3d", "--dtype", "fp32", "--sn", "7", "--step", "2", "--prefetch", "--uniform-loads", "1", "--store-mask", "buffer"]),
     ("2d_tile_buffer_stores", 2, "BOX9", (1, 41, 70), ["--dtype", "fp64", "--store-mask", "buffer"]),
+    # --defer-stores: a completed plane leaves one iteration later (blocks of 1, 2 and many planes; every staging / store path)
+    ("3d_defer_stores", 3, "STAR3", (19, 23, 262), ["--3d", "--dtype", "fp32", "--sn", "7", "--step", "2", "--prefetch", "--defer-stores", "1"]),
+    ("3d_defer_stores_sn1", 3, "STAR3", (9, 11, 140), ["--3d", "--dtype", "fp64", "--sn", "1", "--prefetch", "--prefetch-depth", "2", "--defer-stores", "1"]),
+    ("3d_defer_stores_sn2_noprefetch_buf", 3, "STAR3", (12, 17, 263), ["--3d", "--dtype", "fp32", "--sn", "2", "--defer-stores", "1", "--store-mask", "buffer"]),
+    ("3d_defer_stores_reuse_dma", 3, "STAR3", (19, 23, 264), ["--3d", "--dtype", "fp32", "--sn", "5", "--step", "2", "--dist", "1", "--stage", "dma", "--defer-stores", "1"]),
+    ("3d_defer_stores_window", 3, "STAR3", (19, 23, 262), ["--3d", "--dtype", "fp64", "--sn", "4", "--step", "2", "--schedule", "window", "--prefetch", "--defer-stores", "1", "--uniform-loads", "2"]),
+    ("2d_stream_defer_stores", 2, "BOX25", (1, 61, 268), ["--dtype", "fp32", "--streaming", "--sn", "9", "--prefetch", "--defer-stores", "1"]),
 ]
 
 # --stage dma: planes staged by LDS-DMA into the per-lane-dense LDS image (own region [row][vector][lane], halo pieces by loader task);
@@ -272,7 +279,9 @@ def _emulated_fuzz_jobs(n=14, seed=9):
                 if rnd.random() < 0.2:
                     cl += ["--drain", str(rnd.choice([1, 2]))]
                 if rnd.random() < 0.35 and "--temporal" not in cl and "--cyclic-merge-y" not in cl and (ndim == 3 or "--streaming" in cl):
-                    cl += ["--stage", "dma"]          # LDS-DMA staging (16-byte vectors: the generator rejects the others)
+                    cl += ["--stage", "dma"]
+                if rnd.random() < 0.3:
+                    cl += ["--defer-stores", "1"]          # LDS-DMA staging (16-byte vectors: the generator rejects the others)
                 jobs.append((t.cfgToString(v) + "_" + dtype + "_%dd" % ndim + pts.lower(), ndim, pts, dims, (["--3d"] if ndim == 3 else []) + ["--dtype", dtype] + cl, v[0]))
     return jobs
 

@@ -566,5 +566,11 @@ def test_rccl_exchange_choreography_on_one_gpu(torch_cuda, tmp_path, every):
         (a1, b1, p), (a2, b2, _) = res
         assert torch.equal(a1, a2) and torch.equal(b1, b2)
         assert bool((a1[p.recv_up[0]:p.recv_up[1]] != A0[p.lo:p.lo + p.G].to(dev)).any()), "ghost planes were never exchanged"
+        # bench.py's N > 1 self-check on the device path (seeded global planes, SlabRun through the process group, the wider
+        # no-exchange recomputation, all_reduce of the verdict): a one-rank world is the degenerate case this GPU can run
+        import bench
+        run1 = SlabRun(torch, dist, (L, M, N), H, 2, spec.iterations, 0, 1, sweep, dev, torch.float32, every=1)
+        ok, detail = bench.verify_slab_run(torch, dist, run1, sweep, (L, M, N), H, spec.launches, spec.iterations, 0, 1, dev, torch.float32)
+        assert ok and detail["decomposed_vs_single_domain"]["launches"] == spec.launches
     finally:
         dist.destroy_process_group()
