@@ -130,14 +130,39 @@ def pmc_traffic(workload, option_string):
         return None, "no PMC passes committed for [%s][%s] in %s" % (workload, option_string, path)
 
 
-def cpu_baseline(workload, step, budget_s=15.0, host_slab=None):
-    """Oracle (port) timed on the host cores on a bounded z/y-slab sample of the workload: the first slices of the very
-    array the GPU loop started from (host_slab), or seeded random numbers of the same shape."""
+def cpu_baseline(workload, step, budget_s=15.0, host_slab=None, gpu_first_launch=None, temporal=False):
+    """The CPU leg (the only place bench.py touches oracle/): the oracle (port) timed on the host cores on a bounded z/y-slab
+    sample of the workload -- the first slices of the very array the GPU loop started from (host_slab), or seeded random
+    numbers of the same shape -- and, as the checker, one oracle sweep of the first 2*Halo+12 slices against what the timed GPU
+    kernel wrote there in one launch (gpu_first_launch): bit-exact, except temporal blocking (1e-6 relative fp32 / 1e-12 fp64)."""
     import numpy as np
     import oracle
     w = WORKLOADS[workload]
     spec = oracle.Spec(w["stc"], w["ndim"], step)
     L, M, N = spec.dims
+    dt = np.float32 if w["dtype"] == "fp32" else np.float64
+    check = None
+    if host_slab is not None and gpu_first_launch is not None:
+        h = spec.halo
+        nsl = gpu_first_launch.shape[0] + 2 * h
+        sub = np.ascontiguousarray(host_slab[:nsl], dtype=dt)
+        dst = np.zeros_like(sub)
+        cs = oracle.Spec(w["stc"], w["ndim"], step)
+        if w["ndim"] == 3:
+            cs.set_dims(nsl, M, N)
+        else:
+            cs.set_dims(1, nsl, N)
+        oracle.sweep(cs, sub, dst, contract=1)
+        ref = dst[h:nsl - h]
+        tol = 1e-6 if w["dtype"] == "fp32" else 1e-12
+        if temporal:
+            sel = (slice(None),) + tuple(slice(h, d - h) for d in ref.shape[1:])
+            rel = float(np.max(np.abs(gpu_first_launch[sel].astype(np.float64) - ref[sel]) / np.maximum(np.abs(ref[sel]), 1e-30)))
+            ok = rel <= tol
+        else:
+            ok = bool(np.array_equal(gpu_first_launch, ref))
+            rel = 0.0 if ok else float(np.max(np.abs(gpu_first_launch.astype(np.float64) - ref) / np.maximum(np.abs(ref), 1e-30)))
+        check = {"ok": bool(ok), "max_rel": rel, "slices": int(nsl), "bit_exact_required": not temporal}
     # bounded sample: a slab of the outermost dim (same plane size, same stencil, same dtype)
     if w["ndim"] == 3:
         Ls = min(L, 128)
@@ -147,7 +172,6 @@ def cpu_baseline(workload, step, budget_s=15.0, host_slab=None):
         Ms = min(M, 4096)
         spec.set_dims(1, Ms, N)
         sample = "SAMPLE: %d x %d y-slab of the %d x %d grid" % (Ms, N, M, N)
-    dt = np.float32 if w["dtype"] == "fp32" else np.float64
     if host_slab is not None and tuple(host_slab.shape) == tuple(spec.shape):
         A = np.ascontiguousarray(host_slab, dtype=dt)
         sample += " (the GPU run's own input)"
@@ -170,16 +194,15 @@ def cpu_baseline(workload, step, budget_s=15.0, host_slab=None):
             break
     gst = sweeps * step * interior / el / 1e9
     return dict(value=gst, unit="GStencil/s", cores=oracle.threads(), kind="port",
-                sample="%s, %d sweeps in %.1f s (OpenMP, %d threads)" % (sample, sweeps, el, oracle.threads()))
+                sample="%s, %d sweeps in %.1f s (OpenMP, %d threads)" % (sample, sweeps, el, oracle.threads())), check
 
 
-def verify_timed_kernel(torch, kern, workload, A, B, step, temporal):
-    """What bench.py timed is what the parity tests check: ONE launch of the timed kernel on the run's own input against
-    (1) the emitted gold kernel on the whole grid (the reference's --check path, codegen.hpp:591-627) and (2) the CPU oracle
-    on the first 2*Halo+12 slices.  Bit-exact, except temporal blocking (re-associated: 1e-6 relative fp32 / 1e-12 fp64).
-    A holds the input, B receives the output; returns (ok, details, host copy of the first <= 128 slices of A)."""
-    import numpy as np
-    import oracle
+def verify_timed_kernel(torch, kern, workload, A, B, temporal):
+    """What bench.py timed is what the parity tests check: ONE launch of the timed kernel on the run's own input against the
+    emitted gold kernel on the whole grid (the reference's --check path, codegen.hpp:591-627), plus the untouched ring.
+    Bit-exact, except temporal blocking (re-associated: 1e-6 relative fp32 / 1e-12 fp64).  A holds the input, B receives the
+    output.  Returns (ok, details, host copy of the first <= 128 slices of A, host copy of the first output slices of B) -- the
+    last two feed the CPU leg (cpu_baseline), which compares them with the oracle."""
     w = WORKLOADS[workload]
     h = kern.info["halo"]
     tol = 1e-6 if w["dtype"] == "fp32" else 1e-12
@@ -193,34 +216,18 @@ def verify_timed_kernel(torch, kern, workload, A, B, step, temporal):
         rel = float(((B[inner] - G[inner]).abs() / G[inner].abs().clamp_min(1e-30)).max())
         gold_ok = rel <= tol
     else:
-        rel = 0.0 if torch.equal(B, G) else float(((B[inner] - G[inner]).abs() / G[inner].abs().clamp_min(1e-30)).max())
         gold_ok = torch.equal(B, G)
+        rel = 0.0 if gold_ok else float(((B[inner] - G[inner]).abs() / G[inner].abs().clamp_min(1e-30)).max())
     ring_ok = int(torch.count_nonzero(B)) == int(torch.count_nonzero(B[inner]))      # the ring of the output is never written
     del G
     nsl = min(A.shape[0], 2 * h + 12)
     keep = min(A.shape[0], 128 if w["ndim"] == 3 else 4096)
     host = A[:keep].cpu().numpy()
-    sub = np.ascontiguousarray(host[:nsl])
-    dst = np.zeros_like(sub)
-    spec = oracle.Spec(w["stc"], w["ndim"], step)
-    if w["ndim"] == 3:
-        spec.set_dims(nsl, A.shape[1], A.shape[2])
-    else:
-        spec.set_dims(1, nsl, A.shape[1])
-    oracle.sweep(spec, sub, dst, contract=1)
-    got = B[h:nsl - h].cpu().numpy()
-    ref = dst[h:nsl - h]
-    if temporal:
-        sel = (slice(None),) + tuple(slice(h, d - h) for d in got.shape[1:])
-        orel = float(np.max(np.abs(got[sel].astype(np.float64) - ref[sel]) / np.maximum(np.abs(ref[sel]), 1e-30)))
-        oracle_ok = orel <= tol
-    else:
-        oracle_ok = bool(np.array_equal(got, ref))
-        orel = 0.0 if oracle_ok else float(np.max(np.abs(got.astype(np.float64) - ref) / np.maximum(np.abs(ref), 1e-30)))
-    return (gold_ok and oracle_ok and ring_ok), {
+    first = B[h:nsl - h].cpu().numpy()
+    return bool(gold_ok and ring_ok), {
         "vs_gold_kernel_full_grid": {"ok": bool(gold_ok), "max_rel": rel, "bit_exact_required": not temporal},
-        "vs_cpu_oracle_slab": {"ok": bool(oracle_ok), "max_rel": orel, "slices": int(nsl), "bit_exact_required": not temporal},
-        "ring_untouched": bool(ring_ok), "tolerance": 0.0 if not temporal else tol}, host
+        "vs_cpu_oracle_slab": None,       # filled by the CPU leg (cpu_baseline) unless --no-cpu-baseline
+        "ring_untouched": bool(ring_ok), "tolerance": 0.0 if not temporal else tol}, host, first
 
 
 def _seeded_planes(torch, lo, hi, rest, dtype, device):
@@ -490,11 +497,11 @@ def main(argv=None):
         step1 = side(kern1, STEP1[args.workload], 16) if kern1 is not None else None
         fused2 = side(kernf, TEMPORAL2[args.workload], 32) if kernf is not None else None
         window2 = side(kernw, WINDOW2WG[args.workload], 32) if kernw is not None else None
-        verified, verification, host_slab = None, None, None
+        verified, verification, host_slab, first_out = None, None, None, None
         if not args.no_verify:
             g = torch.Generator(device=dev).manual_seed(1)
             A.copy_(torch.rand(shape, dtype=tdt, device=dev, generator=g))      # the input the timed loop started from
-            verified, verification, host_slab = verify_timed_kernel(torch, kern, args.workload, A, B, step, kinfo.get("stages", 1) > 1)
+            verified, verification, host_slab, first_out = verify_timed_kernel(torch, kern, args.workload, A, B, kinfo.get("stages", 1) > 1)
     else:
         if auto_every:
             args.exchange_every, calibration = measure_exchange_every(torch, dist, (L, M, N) if w["ndim"] == 3 else (M, N), H, prank, pworld, sweep, dev, tdt,
@@ -536,7 +543,7 @@ def main(argv=None):
         kres = sweep.kernel(run.plan.interior[1] - run.plan.interior[0]).resources
         parallelism = "%s-slab x%d%s, RCCL send/recv halo every %d launch(es), overlapped" % ("z" if w["ndim"] == 3 else "y", pworld, " (weak: grid %s)" % "x".join(str(d) for d in ((L, M, N) if w["ndim"] == 3 else (M, N))) if weak else "", args.exchange_every)
         step1 = fused2 = window2 = None
-        verified, verification, host_slab = None, None, None     # the slab kernels' parity is tests/test_gpu_parity.py::test_c4_slab_views_at_full_size
+        verified, verification, host_slab, first_out = None, None, None, None     # the slab kernels' parity is tests/test_gpu_parity.py::test_c4_slab_views_at_full_size
         if not args.no_verify and not rehearse:      # (a rehearsal's self-neighbour exchange is not the physical one)
             verified, verification = verify_slab_run(torch, dist, run, sweep, (L, M, N) if w["ndim"] == 3 else (M, N), H, launches_per_step, iters, prank, pworld, dev, tdt)
 
@@ -580,7 +587,10 @@ def main(argv=None):
         out["two_workgroups_per_cu_kernel"] = window2   # the same fused arithmetic from rotating register windows at 126 VGPRs: two workgroups per CU
         if not args.no_cpu_baseline and pworld == 1:
             sys.path.insert(0, ROOT)
-            out["cpu_baseline"] = cpu_baseline(args.workload, step, host_slab=host_slab)
+            out["cpu_baseline"], oracle_check = cpu_baseline(args.workload, step, host_slab=host_slab, gpu_first_launch=first_out, temporal=kinfo.get("stages", 1) > 1)
+            if oracle_check is not None:       # the CPU leg is also the checker of what was timed
+                out["verification"]["vs_cpu_oracle_slab"] = oracle_check
+                out["verified"] = bool(out["verified"] and oracle_check["ok"])
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out), flush=True)
