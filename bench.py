@@ -38,6 +38,14 @@ WORKLOADS = {
     "c2f64": dict(stc=os.path.join(CFG, "c2_2d5pt_star_8192.stc"), ndim=2, dtype="fp64", name="2d5pt_star 8192^2 fp64 (reference precision and size), iterations 4"),
     "c3f64": dict(stc=os.path.join(CFG, "c3_3d7pt_star_512.stc"), ndim=3, dtype="fp64", name="3d7pt_star 512^3 fp64 (reference precision and size), iterations 4"),
     "c4f64": dict(stc=os.path.join(CFG, "c4_3d7pt_star_1024.stc"), ndim=3, dtype="fp64", name="3d7pt_star 1024^3 fp64 (reference precision), iterations 4"),
+    # the reference's other shipped benchmark directories as they stand (benchmarks/<name>/<name>.stc: 8192^2 / 512^3, fp64, iterations 4);
+    # 3d7pt_star is c3f64 above; 2d9pt_cross is left out: its spec's `iteratioins` typo leaves Iterations 0
+    "s_2d5pt_star": dict(stc=os.path.join(ROOT, "benchmarks", "2d5pt_star", "2d5pt_star.stc"), ndim=2, dtype="fp64", name="2d5pt_star 8192^2 fp64 (shipped spec), iterations 4"),
+    "s_2d5pt_cross": dict(stc=os.path.join(ROOT, "benchmarks", "2d5pt_cross", "2d5pt_cross.stc"), ndim=2, dtype="fp64", name="2d5pt_cross 8192^2 fp64 (shipped spec), iterations 4"),
+    "s_2d9pt_box": dict(stc=os.path.join(ROOT, "benchmarks", "2d9pt_box", "2d9pt_box.stc"), ndim=2, dtype="fp64", name="2d9pt_box 8192^2 fp64 (shipped spec), iterations 4"),
+    "s_2d9pt_star": dict(stc=os.path.join(ROOT, "benchmarks", "2d9pt_star", "2d9pt_star.stc"), ndim=2, dtype="fp64", name="2d9pt_star 8192^2 fp64 (shipped spec), iterations 4"),
+    "s_2d25pt_box": dict(stc=os.path.join(ROOT, "benchmarks", "2d25pt_box", "2d25pt_box.stc"), ndim=2, dtype="fp64", name="2d25pt_box 8192^2 fp64 (shipped spec), iterations 4"),
+    "s_3d9pt_cross": dict(stc=os.path.join(ROOT, "benchmarks", "3d9pt_cross", "3d9pt_cross.stc"), ndim=3, dtype="fp64", name="3d9pt_cross 512^3 fp64 (shipped spec), iterations 4"),
 }
 # tuned generator options per workload (found with drstencil_amd/tuner; logs under profiles/).
 # Headline for the 3D workloads: two time steps per launch with the reference's own --step 2 arithmetic
@@ -65,6 +73,14 @@ TUNED = {
     # (profiles/r02_exp_r2i_diagnostics.log: 0.374 vs 0.388 ms at 512^3, 3.04 vs 3.22 ms at 1024^3), so it stays, with -fno-slp-vectorize (+0.3 %)
     "c3f64": ["--3d", "--dtype", "fp64", "--step", "2", "--bx", "128", "--by", "4", "--block-merge-x", "2", "--block-merge-y", "2", "--sn", "32", "--xcd-remap", "2", "--cc-opt", "-fno-slp-vectorize"],
     "c4f64": ["--3d", "--dtype", "fp64", "--step", "2", "--bx", "128", "--by", "4", "--block-merge-x", "2", "--block-merge-y", "2", "--sn", "32", "--xcd-remap", "2", "--cc-opt", "-fno-slp-vectorize"],
+    # shipped specs: the best exact-arithmetic configurations of profiles/r01_tune_shipped.md (--step 2 like the reference's tuner,
+    # benchmarks/*/tuning.py:110, where its best is a fused kernel; step 1 where only a temporal pipeline -- tolerance-bound -- was faster)
+    "s_2d5pt_star": ["--dtype", "fp64", "--step", "2", "--bx", "128", "--by", "4", "--block-merge-x", "2", "--block-merge-y", "2", "--xcd-remap", "0"],
+    "s_2d5pt_cross": ["--dtype", "fp64", "--step", "2", "--dist", "2", "--bx", "64", "--by", "4", "--block-merge-x", "2", "--block-merge-y", "4", "--xcd-remap", "0"],
+    "s_2d9pt_box": ["--dtype", "fp64", "--step", "2", "--bx", "64", "--by", "4", "--block-merge-x", "2", "--block-merge-y", "4", "--xcd-remap", "0"],
+    "s_2d9pt_star": ["--dtype", "fp64", "--bx", "128", "--by", "4", "--block-merge-x", "2", "--block-merge-y", "2", "--xcd-remap", "0"],
+    "s_2d25pt_box": ["--dtype", "fp64", "--bx", "64", "--by", "2", "--block-merge-x", "2", "--block-merge-y", "8", "--xcd-remap", "0"],
+    "s_3d9pt_cross": ["--3d", "--dtype", "fp64", "--step", "2", "--dist", "2", "--schedule", "scatter"],
 }
 # the same workloads with one time step per launch: highest roofline fraction.  Full-row tiles (256 lanes x 4
 # points = N), 2 lane rows x 4 rows, 4-plane stream blocks, prefetch: the optimum of the exhaustive 1520-configuration

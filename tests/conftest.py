@@ -210,3 +210,8 @@ def pytest_sessionstart(session):
         for r in range(world):
             for every in (1, 2):
                 sw.prebuild(SlabPlan(1024, 2, world, r, every))
+    for world in (2, 4):        # test_c2_yslab_views_at_full_size
+        sw = HipSweep(bench.WORKLOADS["c2"]["stc"], bench.slab_options("c2", world), SLAB_CACHE)
+        for r in range(world):
+            for every in (1, 2):
+                sw.prebuild(SlabPlan(8192, 1, world, r, every))

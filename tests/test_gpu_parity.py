@@ -527,6 +527,51 @@ def test_c4_slab_views_at_full_size(torch_cuda, world, every):
 
 
 @pytest.mark.parametrize("every", [1, 2], ids=["exchange_every_launch", "exchange_every_pair"])
+@pytest.mark.parametrize("world", [2, 4])
+def test_c2_yslab_views_at_full_size(torch_cuda, world, every):
+    """SURVEY 8(f) rank 4, the 2D j-slab decomposition, at BASELINE size: 2d5pt_star 8192^2 fp32 cut into y slabs, what
+    `bench.py --workload c2 --gpus <world>` launches (the one-shot LDS tile kernel on the views of every rank, in turn on this
+    GPU, in-process exchange), bit-equal to the single-domain run."""
+    import bench
+    import drstencil_amd as drs
+    from drstencil_amd.multigpu import HipSweep, SlabRun
+    torch = torch_cuda
+    wl = bench.WORKLOADS["c2"]
+    stc, opts = wl["stc"], bench.slab_options("c2", world)
+    full = drs.Kernel(bench.TUNED["c2"] + [stc])
+    i = full.info
+    M, N, H, step = i["M"], i["N"], i["halo"], i["step"]
+    dev = torch.device("cuda", 0)
+    g = torch.Generator(device="cuda").manual_seed(78)
+    A0 = torch.rand((M, N), dtype=torch.float32, device=dev, generator=g)
+    A_ref = A0.clone(); B_ref = torch.zeros_like(A0)
+    n_ref = full.run(A_ref.data_ptr(), B_ref.data_ptr())
+    torch.cuda.synchronize()
+    hub = _Hub()
+    sweep = HipSweep(stc, opts, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "drstencil_amd", "_kcache"))
+    runs = [SlabRun(torch, _FakeDist(hub, r), (M, N), H, step, i["iterations"], r, world, sweep, dev, torch.float32, every=every) for r in range(world)]
+    for r in runs:
+        r.load_global(lambda lo, hi: A0[lo:hi])
+    t, n = 0, 0
+    while t < i["iterations"]:
+        for src, dst in (("A", "B"), ("B", "A")):
+            for r in runs:
+                if every == 2 and src == "A":
+                    r.launch_local(r.A, r.B)
+                else:
+                    r.launch(getattr(r, src), getattr(r, dst))
+            torch.cuda.synchronize()
+            hub.deliver()
+            assert not hub.pending
+            n += 1
+        t += 2 * step
+    assert n == n_ref
+    for r in runs:
+        p = r.plan
+        assert torch.equal(r.owned(r.A), A_ref[p.z0:p.z1]) and torch.equal(r.owned(r.B), B_ref[p.z0:p.z1]), "rank %d of %d" % (r.rank, world)
+
+
+@pytest.mark.parametrize("every", [1, 2], ids=["exchange_every_launch", "exchange_every_pair"])
 def test_rccl_exchange_choreography_on_one_gpu(torch_cuda, tmp_path, every):
     """The real RCCL transport under SlabRun's stream/event choreography, as far as one GPU can show it: this
     process is the only rank of an RCCL group and plays a middle rank whose two neighbours are itself (what it
