@@ -118,6 +118,17 @@ def slab_options(workload, world, weak=False):
     return opts
 
 
+def slab_alone_options(workload, world, weak=False):
+    """Options of the launches that have the GPU to themselves (the whole-slab launch of a one-exchange-per-pair run): C4's 256 tiles
+    are one workgroup per CU, so one stream block per tile (no z halo, no per-block prologue) is the fastest sweep of a slab of up to 512
+    planes (0.186 vs 0.199 ms at 128 planes); None: the same kernels as the exchanging launches."""
+    if workload == "c4" and world >= 2 and not weak and os.environ.get("DRS_SLAB_ALONE", "1") != "0":      # 0: A/B experiments
+        opts = list(TUNED[workload])
+        opts[opts.index("--sn") + 1] = "1024"
+        return opts
+    return None
+
+
 MIN_WARM_S = 0.25     # untimed warm-up continues (beyond --warmup steps) until the GPU has been busy this long
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak (MI355X_MICROARCH.md: 8.0 TB/s spec)
 
@@ -442,7 +453,8 @@ def main(argv=None):
     else:
         from drstencil_amd.multigpu import HipSweep, SelfNeighbourRun, SlabPlan, SlabRun, measure_exchange_every
         auto_every = args.exchange_every == 0      # decided after the process group is up, from measured sweep / exchange times
-        sweep = HipSweep(w["stc"], opts, os.path.join(ROOT, "drstencil_amd", "_kcache"))
+        sweep = HipSweep(w["stc"], opts, os.path.join(ROOT, "drstencil_amd", "_kcache"),
+                         alone_opts=None if args.kernel_args else slab_alone_options(args.workload, pworld, args.scaling == "weak"))
         for r in (range(pworld) if args.prebuild_only else (prank,)):
             for ev in ((1, 2) if auto_every else (args.exchange_every,)):      # both modes' kernels: built (cache hits) before HIP is up
                 sweep.prebuild(SlabPlan(L if w["ndim"] == 3 else M, H, pworld, r, ev))

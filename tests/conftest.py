@@ -206,7 +206,7 @@ def pytest_sessionstart(session):
     import bench
     from gpu_cases import C4_SLAB_WORLDS
     for world in C4_SLAB_WORLDS:
-        sw = HipSweep(bench.WORKLOADS["c4"]["stc"], bench.slab_options("c4", world), SLAB_CACHE)
+        sw = HipSweep(bench.WORKLOADS["c4"]["stc"], bench.slab_options("c4", world), SLAB_CACHE, alone_opts=bench.slab_alone_options("c4", world))
         for r in range(world):
             for every in (1, 2):
                 sw.prebuild(SlabPlan(1024, 2, world, r, every))

@@ -499,7 +499,8 @@ def test_c4_slab_views_at_full_size(torch_cuda, world, every):
     n_ref = full.run(A_ref.data_ptr(), B_ref.data_ptr())
     torch.cuda.synchronize()
     hub = _Hub()
-    sweep = HipSweep(stc, opts, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "drstencil_amd", "_kcache"))
+    sweep = HipSweep(stc, opts, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "drstencil_amd", "_kcache"),
+                     alone_opts=bench.slab_alone_options("c4", world))        # the whole-slab launches of every = 2: one stream block per tile
     runs = [SlabRun(torch, _FakeDist(hub, r), (L, M, N), H, step, i["iterations"], r, world, sweep, dev, torch.float32, every=every) for r in range(world)]
     used_pair = False
     for r in runs:
