@@ -102,6 +102,8 @@ MI355X options:
                         plane's loads were issued (its write latency runs under that plane's work).
 --drain <0|1|2>         s_waitcnt vmcnt(0) before every plane's prefetch loads (1) or before its LDS staging (2).
 --cc-opt <flag>         Extra hipcc flag for this kernel (repeatable), e.g. --cc-opt -fno-slp-vectorize.
+--exact-x <0|1>         1 (default): the x halo columns are fetched by the halo loader lanes; 0: overlapped tiles in x (the
+                        tile's outermost lanes load them with the row and own nothing, e.g. --bx 34: 136 columns own 128).
 --clamp-loads <0|1>     1 (default): branch-free loads -- lanes outside the grid read the plane origin (their
                         values never reach a stored output); 0: loads under per-lane guards.
 --halo-spread <0|1>     Spread the halo loader tasks over all wavefronts (default 0: the first lanes take them).
@@ -162,6 +164,7 @@ inline GenResult generate(const std::vector<std::string> &args /* argv[1..] */) 
         else if (a == "--xrim") { if (!str_opt(o.xrim)) break; }
         else if (a == "--schedule") { if (!str_opt(o.schedule)) break; o.schedule_set = true; }
         else if (a == "--exact-y") { if (!int_opt(o.exact_y, nullptr)) break; }
+        else if (a == "--exact-x") { if (!int_opt(o.exact_x, nullptr)) break; }
         else if (a == "--xedge-select") { if (!int_opt(o.xedge_select, nullptr)) break; }
         else if (a == "--debug-skip") { if (!int_opt(o.debug_skip, nullptr)) break; }
         else if (a == "--debug-drop-barrier") { if (!int_opt(o.debug_drop_barrier, nullptr)) break; }

@@ -65,6 +65,9 @@ struct GenOptions {
     int exact_y = -1;            // 1: halo loaders also fetch the source plane's y halo rows (every tile row owned);
                                  // 0: overlapped tiles; -1 auto: 1 for single-stage kernels, 0 for temporal pipelines
                                  // (measured: +3 % at step 1, -12 % on the 2-stage pipeline whose lanes own only 2 rows)
+    int exact_x = 1;             // 1: the x halo columns of the source plane come from the halo loader lanes (16-byte pieces, one per row and side);
+                                 // 0: overlapped tiles in x -- the tile's outermost lanes load the halo columns as part of the row (one longer
+                                 // contiguous run per row, e.g. 34 lanes x 4 = 136 columns own 128) and store nothing
     int debug_skip = 0;          // TIMING EXPERIMENTS ONLY (results are wrong; such kernels load only with DRS_EXPERIMENTS=1), a bit mask of what the
                                  // kernel leaves out so that the parts of a plane iteration can be timed separately: 1 the x-halo loader tasks,
                                  // 2 the y-halo loader tasks, 4 every tap that is not on the lane's own point (5 of 25 FMAs left for the fused
@@ -129,6 +132,7 @@ struct KernelPlan {
     int stages = 1;          // on-chip time steps per launch (temporal blocking); 1 = apply `taps` once
     int oym = 0, oyp = 0;    // rows at the tile's y edges that are not owned (halo of all stages)
     bool exact_y = true;     // y halo rows of the source plane come from the halo loaders
+    bool exact_x = true;     // x halo columns of the source plane come from the halo loaders (false: the tile's edge lanes load them)
     int AL = 0;              // columns at each x edge of the lane tile that are not owned (stages > 1)
     int OX = 0;              // columns owned per tile
     int zl = 0, zh = 0, hym = 0, hyp = 0, hxm = 0, hxp = 0;

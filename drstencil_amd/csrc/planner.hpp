@@ -188,7 +188,9 @@ inline KernelPlan make_plan(const Stencil &st, const GenOptions &o_in, const std
     if (p.OY < 1) { p.error = "tile has no rows left after the y halo"; return p; }
     if (p.PADL > p.TX || p.PADR > p.TX) { p.error = "x halo wider than the tile"; return p; }
     // stages > 1: intermediate planes have no x halo, so each extra stage loses hx columns per side
+    p.exact_x = (o.exact_x != 0);
     p.AL = (p.stages > 1) ? round_up((p.stages - 1) * std::max(p.hxm, p.hxp), vl) : 0;
+    if (!p.exact_x) p.AL += round_up(std::max(p.hxm, p.hxp), vl);      // the source plane's x halo is part of the lane tile too
     p.OX = p.TX - 2 * p.AL;
     if (p.OX < 1) { p.error = "tile has no columns left after the x halo of the fused stages"; return p; }
     const int H = st.halo;
@@ -206,6 +208,7 @@ inline KernelPlan make_plan(const Stencil &st, const GenOptions &o_in, const std
         if (p.cyclic_y) { p.error = "--stage dma needs block y merging"; return p; }
         if (!o.clamp_loads || o.halo_spread) { p.error = "--stage dma needs --clamp-loads 1 --halo-spread 0"; return p; }
         if (p.has_y && !p.exact_y) { p.error = "--stage dma needs --exact-y 1"; return p; }
+        if (!p.exact_x) { p.error = "--stage dma needs --exact-x 1"; return p; }
         p.dma = true;
         p.prefetch = false;      // the look-ahead is the DMA itself
     }

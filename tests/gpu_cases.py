@@ -69,6 +69,11 @@ _add("3d7_fp64_ul2_buf_drain1", 3, "t3_star_odd", "--dtype", "fp64", "--sn", "5"
 _add("3d7_fp32_t2_ul2_drain2", 3, "t3_star", "--dtype", "fp32", "--step", "2", "--temporal", "1", "--by", "8", "--block-merge-y", "4", "--sn", "16", "--prefetch", "--uniform-loads", "2", "--drain", "2")
 _add("2d25_fp32_stream_buf", 2, "t2_box25", "--dtype", "fp32", "--streaming", "--prefetch", "--uniform-loads", "2", "--store-mask", "buffer")
 _add("2d5_fp64_tile_buf", 2, "t2_star", "--dtype", "fp64", "--store-mask", "buffer")
+# overlapped tiles in x (--exact-x 0), deferred stores
+_add("3d7_fp32_s2_overlap_x", 3, "t3_star", "--dtype", "fp32", "--step", "2", "--exact-x", "0", "--bx", "34", "--by", "7", "--block-merge-y", "2", "--sn", "16", "--prefetch")
+_add("2d25_fp64_stream_overlap_x", 2, "t2_box25", "--dtype", "fp64", "--streaming", "--exact-x", "0", "--bx", "34")
+_add("3d7_fp32_s2_defer_stores", 3, "t3_star", "--dtype", "fp32", "--step", "2", "--sn", "16", "--bx", "32", "--by", "8", "--block-merge-y", "2", "--prefetch", "--prefetch-depth", "1", "--defer-stores", "1")
+_add("3dodd_fp64_defer_stores_dma", 3, "t3_odd", "--dtype", "fp64", "--stage", "dma", "--defer-stores", "1", "--sn", "7")
 
 # --stage dma (round 2): planes staged by LDS-DMA (global_load_lds_dwordx4) into the per-lane-dense LDS image, tile-edge lanes re-reading
 # from the halo regions; every schedule, both x-rim paths, box corners, wide halos (hx > points per lane), ragged grids

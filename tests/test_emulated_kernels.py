@@ -72,6 +72,12 @@ VARIANTS = [
     ("2d_tile_branch_stores", 2, "BOX9", (1, 41, 70), ["--dtype", "fp64", "--store-mask", "branch"]),
     ("3d_buffer_stores_uniform_loads", 3, "STAR3", (19, 23, 262), ["--3d", "--dtype", "fp32", "--sn", "7", "--step", "2", "--prefetch", "--uniform-loads", "1", "--store-mask", "buffer"]),
     ("2d_tile_buffer_stores", 2, "BOX9", (1, 41, 70), ["--dtype", "fp64", "--store-mask", "buffer"]),
+    # --exact-x 0: overlapped tiles in x (the tile's outermost lanes load the halo columns with the row and own nothing)
+    ("3d_overlap_x_bx34", 3, "STAR3", (19, 23, 300), ["--3d", "--dtype", "fp32", "--sn", "7", "--step", "2", "--prefetch", "--exact-x", "0", "--bx", "34", "--by", "7", "--block-merge-y", "2"]),
+    ("3d_overlap_x_fp64_lds", 3, "STAR3", (12, 17, 263), ["--3d", "--dtype", "fp64", "--sn", "3", "--exact-x", "0", "--xrim", "lds", "--bx", "18", "--by", "8"]),
+    ("3d_overlap_x_reuse", 3, "STAR3", (19, 23, 300), ["--3d", "--dtype", "fp32", "--sn", "5", "--step", "2", "--dist", "1", "--exact-x", "0", "--bx", "34", "--by", "7", "--block-merge-y", "2"]),
+    ("2d_overlap_x_box25_stream", 2, "BOX25", (1, 61, 268), ["--dtype", "fp32", "--streaming", "--sn", "9", "--prefetch", "--exact-x", "0", "--bx", "34"]),
+    ("2d_overlap_x_tile", 2, "BOX9", (1, 41, 140), ["--dtype", "fp64", "--exact-x", "0", "--bx", "18", "--by", "8"]),
     # --defer-stores: a completed plane leaves one iteration later (blocks of 1, 2 and many planes; every staging / store path)
     ("3d_defer_stores", 3, "STAR3", (19, 23, 262), ["--3d", "--dtype", "fp32", "--sn", "7", "--step", "2", "--prefetch", "--defer-stores", "1"]),
     ("3d_defer_stores_sn1", 3, "STAR3", (9, 11, 140), ["--3d", "--dtype", "fp64", "--sn", "1", "--prefetch", "--prefetch-depth", "2", "--defer-stores", "1"]),
