@@ -184,34 +184,49 @@ def pytest_sessionstart(session):
     with ProcessPoolExecutor(max_workers=min(16, os.cpu_count() or 1)) as ex:
         bad = [r for r in ex.map(_build_kernel, jobs) if r]
         list(ex.map(_build_kernel, fuzz_args))
-    assert not bad, "kernel builds failed:\n" + "\n".join(bad)
+    # a kernel that cannot be built fails the tests that use it (their drs.Kernel call raises: after HIP is up a cache miss is an
+    # error, not a compiler run) -- not the whole session
+    if bad:
+        sys.stderr.write("conftest: %d kernel build(s) failed at session start:\n%s\n" % (len(bad), "\n".join(bad)))
     # slab-view kernels of test_slab_decomposition_on_one_gpu (compiled here, before HIP is up)
-    import tempfile
     from drstencil_amd.multigpu import HipSweep, SlabPlan
     global SLAB_CACHE
     SLAB_CACHE = os.path.join(ROOT, "drstencil_amd", "_kcache")
     from gpu_cases import SLAB_CASES
-    for cid, world, stencil, ndim, opts in SLAB_CASES:
-        step = int(opts[opts.index("--step") + 1]) if "--step" in opts else 1
-        spec = drs.Spec(stcp(stencil), ndim, step)
-        cut = spec.dims[0] if ndim == 3 else spec.dims[1]
-        sw = HipSweep(stcp(stencil), opts, SLAB_CACHE)
-        drs.Kernel(opts + [stcp(stencil)])
-        for r in range(world):
-            for every in (1, 2):
-                sw.prebuild(SlabPlan(cut, spec.halo, world, r, every))
-    # the one-rank world of test_rccl_exchange_choreography_on_one_gpu's bench.verify_slab_run call: the whole-grid view
-    HipSweep(stcp("t3_star"), ["--3d", "--dtype", "fp32", "--step", "2", "--sn", "16"], SLAB_CACHE).kernel(drs.Spec(stcp("t3_star"), 3, 2).dims[0])
-    # ... and of test_c4_slab_views_at_full_size: what bench.py --gpus 2/4/8 launches
     import bench
     from gpu_cases import C4_SLAB_WORLDS
+
+    def prebuild(what, fn):
+        try:
+            fn()
+        except Exception as e:       # the tests that need these kernels fail on their own drs.Kernel call; the session goes on
+            sys.stderr.write("conftest: prebuilding %s failed: %s\n" % (what, str(e)[-300:]))
+
+    for cid, world, stencil, ndim, opts in SLAB_CASES:
+        def slab_case(world=world, stencil=stencil, ndim=ndim, opts=opts):
+            step = int(opts[opts.index("--step") + 1]) if "--step" in opts else 1
+            spec = drs.Spec(stcp(stencil), ndim, step)
+            cut = spec.dims[0] if ndim == 3 else spec.dims[1]
+            sw = HipSweep(stcp(stencil), opts, SLAB_CACHE)
+            drs.Kernel(opts + [stcp(stencil)])
+            for r in range(world):
+                for every in (1, 2):
+                    sw.prebuild(SlabPlan(cut, spec.halo, world, r, every))
+        prebuild("slab case " + cid, slab_case)
+    # the one-rank world of test_rccl_exchange_choreography_on_one_gpu's bench.verify_slab_run call: the whole-grid view
+    prebuild("one-rank view", lambda: HipSweep(stcp("t3_star"), ["--3d", "--dtype", "fp32", "--step", "2", "--sn", "16"], SLAB_CACHE).kernel(drs.Spec(stcp("t3_star"), 3, 2).dims[0]))
+    # ... and of test_c4_slab_views_at_full_size: what bench.py --gpus 2/4/8 launches
     for world in C4_SLAB_WORLDS:
-        sw = HipSweep(bench.WORKLOADS["c4"]["stc"], bench.slab_options("c4", world), SLAB_CACHE, alone_opts=bench.slab_alone_options("c4", world))
-        for r in range(world):
-            for every in (1, 2):
-                sw.prebuild(SlabPlan(1024, 2, world, r, every))
+        def c4(world=world):
+            sw = HipSweep(bench.WORKLOADS["c4"]["stc"], bench.slab_options("c4", world), SLAB_CACHE, alone_opts=bench.slab_alone_options("c4", world))
+            for r in range(world):
+                for every in (1, 2):
+                    sw.prebuild(SlabPlan(1024, 2, world, r, every))
+        prebuild("C4 slab views, world %d" % world, c4)
     for world in (2, 4):        # test_c2_yslab_views_at_full_size
-        sw = HipSweep(bench.WORKLOADS["c2"]["stc"], bench.slab_options("c2", world), SLAB_CACHE)
-        for r in range(world):
-            for every in (1, 2):
-                sw.prebuild(SlabPlan(8192, 1, world, r, every))
+        def c2(world=world):
+            sw = HipSweep(bench.WORKLOADS["c2"]["stc"], bench.slab_options("c2", world), SLAB_CACHE)
+            for r in range(world):
+                for every in (1, 2):
+                    sw.prebuild(SlabPlan(8192, 1, world, r, every))
+        prebuild("C2 y-slab views, world %d" % world, c2)
