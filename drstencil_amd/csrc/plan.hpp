@@ -28,6 +28,12 @@
 //                       window read"), else read on arrival and carried in registers.
 //   --step n            fused stencil (exact reference arithmetic) or, with --temporal 1,
 //                       n on-chip applications of the one-step stencil (temporal blocking)
+// MI355X-only knobs (round 2; each measured, see DESIGN.md section 3 -- the defaults are what measured fastest):
+//   --schedule          scatter | reuse | window: how reuse along the streamed dimension is split between resident planes and carried sums
+//   --stage reg|dma     arriving planes staged through VGPRs (software prefetch) or by LDS-DMA
+//   --uniform-loads, --store-mask, --drain, --defer-stores   the memory pipeline of the streaming loop (s_waitcnt vmcnt bookkeeping)
+//   --exact-x/--exact-y halo columns / rows from loader lanes (1) or overlapped tiles (0)
+//   --cc-opt            per-kernel compiler flags (the bench kernels use -fno-slp-vectorize)
 #pragma once
 #include <string>
 #include <vector>
