@@ -65,11 +65,13 @@ def main():
                     cl += ["--defer-stores", "1"]
                 jobs.append((ndim, dtype, (["--3d"] if ndim == 3 else []) + ["--dtype", dtype] + cl + [stc], dims))
     t0 = time.time()
-    with ProcessPoolExecutor(max_workers=16) as ex:
+    with ProcessPoolExecutor(max_workers=int(os.environ.get("FUZZ_JOBS", "16"))) as ex:
         errs = list(ex.map(build, jobs))
     ok = [j for j, e in zip(jobs, errs) if e is None]
     rej = [e for e in errs if e is not None]
     print("built %d kernels in %.0f s; %d rejected or refused (%d for scratch spills)" % (len(ok), time.time() - t0, len(rej), sum("scratch" in e for e in rej)), flush=True)
+    if os.environ.get("FUZZ_BUILD_ONLY"):   # fill the kernel cache on a box without a GPU; the GPU run then finds every kernel built
+        return
     kerns = [(j, drs.Kernel(j[2])) for j in ok]
     import torch
     bad = exact = 0

@@ -80,7 +80,7 @@ def main():
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 120
     jobs = make_jobs(n, int(sys.argv[2]) if len(sys.argv) > 2 else 1)
     t0 = time.time()
-    with ProcessPoolExecutor(max_workers=16) as ex:
+    with ProcessPoolExecutor(max_workers=int(os.environ.get("FUZZ_JOBS", "16"))) as ex:
         errs = list(ex.map(build, jobs))
     ok_jobs = [j for j, e in zip(jobs, errs) if e is None]
     rejected = [e for e in errs if e is not None]
@@ -88,6 +88,8 @@ def main():
           % (len(ok_jobs), time.time() - t0, len(rejected), sum(1 for e in rejected if "scratch" in e)), flush=True)
     for e in rejected[:5]:
         print("  rejected:", e)
+    if os.environ.get("FUZZ_BUILD_ONLY"):   # fill the kernel cache on a box without a GPU; the GPU run then finds every kernel built
+        return
     kerns = [(j, drs.Kernel(j[3])) for j in ok_jobs]
     import torch
     bad = 0
