@@ -311,6 +311,17 @@ drs_kernel *drs_kernel_build(int argc, const char *const *argv, const char *cach
                                  "256-lane workgroup (DRS_ALLOW_SCRATCH=1 loads it anyway)\n");
         return nullptr;
     }
+    // The same goes for a kernel that ran out of SCALAR registers: the compiler then keeps the loop's addressing state (plane
+    // pointers, buffer descriptors, fp64 coefficient pairs) in VGPR lanes behind v_writelane / v_readlane.  The round-2 fuzz
+    // found one such kernel (256 VGPRs + 244 AGPRs + 517 spilled SGPRs) miscompiled: right at -O1, in the emulator and with
+    // any of a dozen unrelated backend passes switched off, wrong at -O3 (profiles/r02_fuzz_sgpr_spill_miscompile.md).
+    const long sspill = remark_value(resources, "\"sgpr_spill\":");
+    if (sspill > 0 && !(allow && allow[0] == '1')) {
+        if (log) *log = dup_cstr("drstencil: kernel dr_" + r.plan.name + " spills " + std::to_string(sspill) + " scalar registers " + resources +
+                                 "-- the configuration exceeds the register file: use a smaller tile (--by, --block-merge-y), fewer planes in flight "
+                                 "(--prefetch-depth, --sn) or a lower --step (DRS_ALLOW_SCRATCH=1 loads it anyway)\n");
+        return nullptr;
+    }
     // kernels with barriers removed (--debug-drop-barrier: timing experiments, wrong results) load only when asked for
     if (r.opt.debug_drop_barrier || r.opt.debug_skip) {
         const char *ex = getenv("DRS_EXPERIMENTS");

@@ -60,7 +60,8 @@ const char *drs_kernel_path(const drs_kernel *k);   /* the loaded shared object 
 /* JSON: vgprs, agprs, sgprs, scratch_bytes_per_lane, sgpr_spill, vgpr_spill, occupancy_waves_per_simd, lds_bytes of
  * dr_<name> (with --pair-launch: the maximum over dr_<name> and dr2_<name>) as reported by hipcc -- what the reference reads
  * from `ncu --set full`, getGpuMetrics.py:9 -- plus "verified": 1 when every field was found in the compiler's report.
- * drs_kernel_build refuses (NULL + log): a kernel that spills to scratch (DRS_ALLOW_SCRATCH=1 overrides), a kernel whose
+ * drs_kernel_build refuses (NULL + log): a kernel that spills to scratch or spills scalar registers (sgpr_spill > 0;
+ * DRS_ALLOW_SCRATCH=1 overrides either), a kernel whose
  * report could not be read (DRS_ALLOW_UNVERIFIED=1), a cache miss once this process has launched a kernel or when
  * DRS_NO_COMPILE=1 (hipcc is a child process: build first, launch afterwards), and --debug-drop-barrier kernels
  * (wrong results by design) without DRS_EXPERIMENTS=1. */

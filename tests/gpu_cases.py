@@ -28,6 +28,13 @@ for dt in ("fp32", "fp64"):
     _add("2d25_%s_tile" % dt, 2, "t2_box25", "--dtype", dt)
     _add("2d25_%s_stream_dpp" % dt, 2, "t2_box25", "--dtype", dt, "--streaming", "--xrim", "dpp", "--prefetch")
 _add("3d7_fp32_step3", 3, "t3_star", "--dtype", "fp32", "--step", "3", "--sn", "16")
+# every tap ahead along the streamed dimension (none on the output's own plane / row): found by tests/fuzz_shapes.py, seed 31
+_add("2d_ahead_fp64_stream_scatter", 2, "t2_ahead", "--dtype", "fp64", "--streaming", "--sn", "32", "--prefetch")
+_add("2d_ahead_fp32_stream_step2", 2, "t2_ahead", "--dtype", "fp32", "--streaming", "--sn", "128", "--step", "2", "--dist", "2", "--schedule", "scatter")
+_add("2d_ahead_fp64_tile_step2", 2, "t2_ahead", "--dtype", "fp64", "--step", "2")
+_add("3d_ahead_fp32_scatter", 3, "t3_ahead", "--dtype", "fp32", "--sn", "8", "--schedule", "scatter", "--prefetch")
+_add("3d_ahead_fp64_step2_reuse", 3, "t3_ahead", "--dtype", "fp64", "--sn", "8", "--step", "2", "--dist", "2")
+_add("3d_ahead_fp64_window_dma", 3, "t3_ahead", "--dtype", "fp64", "--sn", "8", "--schedule", "window", "--stage", "dma")
 _add("3d7_fp32_eager", 3, "t3_star", "--dtype", "fp32", "--lazy-rims", "0", "--prefetch")
 _add("3d7_fp32_cyclicy", 3, "t3_star", "--dtype", "fp32", "--cyclic-merge-y", "3", "--by", "2", "--bx", "32", "--sn", "9")
 _add("3d7_fp32_bx128", 3, "t3_star", "--dtype", "fp32", "--bx", "128", "--by", "2", "--block-merge-y", "2", "--xrim", "dpp")

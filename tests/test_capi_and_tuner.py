@@ -105,6 +105,24 @@ def test_kernel_resources_and_scratch_refusal(monkeypatch):
     assert k2.resources["scratch_bytes_per_lane"] > 0
 
 
+def test_scalar_register_spills_are_refused(monkeypatch):
+    """A kernel that ran out of scalar registers (plane pointers, descriptors and fp64 coefficient pairs behind v_writelane /
+    v_readlane) but not of vector registers: the round-2 fuzz found one of these miscompiled at -O3 (right at -O1, in the
+    emulator and with unrelated backend passes off, profiles/r02_fuzz_sgpr_spill_miscompile.md), so the runtime refuses them
+    like kernels that spill to scratch."""
+    stc = os.path.join(ROOT, "tests", "stc", "t3_odd.stc")
+    args = ["--3d", "--dtype", "fp64", "--bx", "16", "--by", "16", "--sn", "64", "--step", "3", "--dist", "3", "--block-merge-x", "2", "--block-merge-y", "4",
+            "--prefetch", "--prefetch-depth", "4", "--xcd-remap", "0", "--schedule", "scatter", "--uniform-loads", "2", "--stage", "dma", stc]
+    monkeypatch.setenv("DRS_ALLOW_SCRATCH", "1")
+    res = drs.Kernel(args).resources
+    if not (res["sgpr_spill"] > 0 and res["scratch_bytes_per_lane"] == 0):
+        pytest.skip("this compiler fits the kernel's scalar state: %r" % res)
+    monkeypatch.delenv("DRS_ALLOW_SCRATCH")
+    with pytest.raises(RuntimeError) as e:
+        drs.Kernel(args)
+    assert "scalar registers" in str(e.value) and "sgpr_spill" in str(e.value)
+
+
 def test_cache_key_keeps_the_whole_hash_for_long_names(tmp_path):
     """A .stc whose base name is longer than the readable part of the cache key: two option sets (or dtypes) must still
     get two different cached kernels (the round-1 key was a 64-byte buffer, so a long name truncated the hash away and

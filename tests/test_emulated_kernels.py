@@ -236,6 +236,16 @@ ASYM = [
     ("3d_mixed_reach", 3, [(0, 0, 0, 0.3), (-2, 0, 0, 0.1), (2, 0, 0, 0.1), (1, 0, 0, 0.05), (0, -1, 0, 0.2), (0, 1, 0, 0.1), (0, 0, -2, 0.05), (0, 0, 1, 0.1)], (15, 12, 150), ["--3d", "--dtype", "fp32", "--sn", "4", "--prefetch", "--dist", "2"]),
     ("3d_mixed_reach_temporal", 3, [(0, 0, 0, 0.3), (-1, 0, 0, 0.1), (1, 0, 0, 0.1), (0, -1, 0, 0.2), (0, 1, 0, 0.1), (0, 0, -1, 0.05), (0, 0, 1, 0.15)], (15, 17, 150), ["--3d", "--dtype", "fp64", "--sn", "4", "--step", "2", "--temporal", "1", "--by", "4", "--block-merge-y", "2"]),
     ("2d_upwind_rows", 2, [(0, 0, 0.5), (1, 0, 0.2), (2, 0, 0.1), (0, 1, 0.1), (0, 2, 0.1)], (1, 33, 70), ["--dtype", "fp64", "--dist", "1"]),
+    # every tap AHEAD along the streamed dimension (nothing on the output's own plane or row): the partial sum starts on a later
+    # plane than the first one it is carried over (tests/fuzz_shapes.py seed 31 found the scatter schedule starting it nowhere)
+    ("2d_taps_ahead_stream_scatter", 2, [(1, 0, 0.14), (1, 2, 0.13), (2, 0, 0.21), (1, 1, 0.2), (1, -2, 0.2)], (1, 41, 90), ["--dtype", "fp64", "--streaming", "--sn", "6"]),
+    ("2d_taps_ahead_stream_step2", 2, [(1, 0, 0.14), (1, 2, 0.13), (2, 0, 0.21), (1, 1, 0.2), (1, -2, 0.2)], (1, 41, 90), ["--dtype", "fp32", "--streaming", "--sn", "6", "--step", "2", "--prefetch"]),
+    ("2d_taps_ahead_stream_temporal2", 2, [(1, 0, 0.15), (1, 2, 0.1), (2, 0, 0.2), (1, 1, 0.2), (1, -2, 0.2)], (1, 41, 90), ["--dtype", "fp64", "--streaming", "--sn", "7", "--step", "2", "--temporal", "1"]),
+    ("2d_taps_ahead_tile", 2, [(1, 0, 0.14), (1, 2, 0.13), (2, 0, 0.21), (1, 1, 0.2), (1, -2, 0.2)], (1, 41, 90), ["--dtype", "fp64", "--step", "2"]),
+    ("3d_taps_ahead_scatter", 3, [(1, 0, 0, 0.3), (2, 0, 0, 0.1), (1, 1, 0, 0.2), (1, 0, -1, 0.15), (2, -1, 1, 0.1)], (15, 14, 140), ["--3d", "--dtype", "fp32", "--sn", "4", "--schedule", "scatter", "--prefetch"]),
+    ("3d_taps_ahead_step2", 3, [(1, 0, 0, 0.3), (2, 0, 0, 0.1), (1, 1, 0, 0.2), (1, 0, -1, 0.15), (2, -1, 1, 0.1)], (17, 16, 140), ["--3d", "--dtype", "fp64", "--sn", "5", "--step", "2"]),
+    ("3d_taps_ahead_reuse_dma", 3, [(1, 0, 0, 0.3), (2, 0, 0, 0.1), (1, 1, 0, 0.2), (1, 0, -1, 0.15), (2, -1, 1, 0.1)], (15, 14, 140), ["--3d", "--dtype", "fp64", "--sn", "4", "--dist", "1", "--stage", "dma"]),
+    ("3d_taps_ahead_temporal2", 3, [(1, 0, 0, 0.3), (2, 0, 0, 0.1), (1, 1, 0, 0.2), (1, 0, -1, 0.15), (2, -1, 1, 0.1)], (17, 20, 140), ["--3d", "--dtype", "fp64", "--sn", "4", "--step", "2", "--temporal", "1", "--by", "4", "--block-merge-y", "2"]),
     ("2d_upwind_rows_stream", 2, [(0, 0, 0.5), (1, 0, 0.2), (2, 0, 0.1), (0, 1, 0.1), (0, 2, 0.1)], (1, 33, 70), ["--dtype", "fp32", "--streaming", "--sn", "6", "--dist", "1", "--xrim", "lds"]),
 ]
 
