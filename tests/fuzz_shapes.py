@@ -17,7 +17,7 @@ from concurrent.futures import ProcessPoolExecutor
 import fuzz_parity as fp
 
 dropped = [0]         # configurations the tuner's spill model kept from the compiler
-MAX_TAPS = 420        # fused point count above which a step is not tried (compile time)
+MAX_TAPS = int(os.environ.get("FUZZ_MAX_TAPS", "420"))        # fused point count above which a step is not tried (compile time)
 
 
 def random_shape(rnd, ndim, h):
@@ -68,8 +68,11 @@ def make_jobs(nshapes, per, seed):
         h = rnd.choice([1, 1, 2] if ndim == 3 else [1, 2, 2, 3])
         pts, mixed = random_shape(rnd, ndim, h)
         dims = (rnd.randint(18 + 2 * h, 40), rnd.randint(30, 70), rnd.randint(130, 300)) if ndim == 3 else (1, rnd.randint(90, 260), rnd.randint(200, 600))
+        if rnd.random() < 0.25:     # grids barely larger than the ring of a 3-step kernel, narrower than a tile, a vector or a wavefront's row
+            lo = 6 * h + 1
+            dims = (rnd.randint(lo, lo + 5), rnd.randint(lo, lo + 9), rnd.randint(lo, 48)) if ndim == 3 else (1, rnd.randint(lo, lo + 9), rnd.randint(lo, 70))
         stc = os.path.join(out, "shape%d_s%d_%dd_o%d.stc" % (seed, s, ndim, h))
-        write_stc(stc, ndim, dims, 4, pts)
+        write_stc(stc, ndim, dims, rnd.randint(1, 7), pts)     # iterations: 2 * ceil(iterations / (2 * step)) launches (codegen.hpp:581-584)
         distinct = len(set(p[:-1] for p in pts))
         steps = tuple(st for st in (1, 2, 3) if min((2 * h * st + 1) ** ndim, distinct ** st) <= MAX_TAPS)
         dists = {}
