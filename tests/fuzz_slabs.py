@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Randomised sweep of the multi-GPU slab path on ONE GPU: random stencil shapes (tests/fuzz_shapes.py: one-sided, sparse,
-dense, orders 1-2), random world sizes 2-5, both exchange modes, a few option sets per shape.  Every rank of the world
+dense, orders 1-2), random world sizes 2-8, both exchange modes, a few option sets per shape, with and without separate
+"alone" kernels for the launches that run without an exchange beside them (bench.slab_alone_options' role).  Every rank of the world
 runs in turn on this GPU through the product SlabRun + HipSweep code (slab views, boundary/interior launches, the
 --pair-launch boundary kernel of middle ranks, ghost planes, streams and events; the transport is an in-process mailbox) and the
 owned planes of every rank must equal the single-domain run of the same kernel bit for bit -- the property
@@ -23,7 +24,7 @@ OPTION_SETS_2D = [[], ["--streaming", "--sn", "16"], ["--streaming", "--sn", "32
 
 
 def make_jobs(nshapes, seed):
-    """(stc, ndim, step, halo, dims, dtype, options, world, every) per job."""
+    """(stc, ndim, step, halo, dims, dtype, options, world, every, alone options or None) per job."""
     rnd = random.Random(seed)
     out = os.path.join(ROOT, "gpurun_out", "fuzz_slabs"); os.makedirs(out, exist_ok=True)
     jobs = []
@@ -34,8 +35,8 @@ def make_jobs(nshapes, seed):
         d1, d2 = fs.legal_dists(pts, 1), fs.legal_dists(pts, 2)
         if not d1:
             continue
-        # the slab dimension is long enough for 5 ranks of at least 2*step*halo planes each
-        dims = (rnd.randint(44, 90), rnd.randint(20, 40), rnd.randint(70, 200)) if ndim == 3 else (1, rnd.randint(60, 200), rnd.randint(150, 500))
+        # the slab dimension is long enough for a handful of ranks of at least 2 * every * step * halo planes each (thinner: refused)
+        dims = (rnd.randint(44, 170), rnd.randint(20, 40), rnd.randint(70, 200)) if ndim == 3 else (1, rnd.randint(60, 300), rnd.randint(150, 500))
         stc = os.path.join(out, "slab%d_s%d_%dd_o%d.stc" % (seed, s, ndim, h))
         write_stc(stc, ndim, dims, rnd.choice([2, 4, 6]), pts)
         for opt in rnd.sample(OPTION_SETS_3D if ndim == 3 else OPTION_SETS_2D, 2):
@@ -45,15 +46,18 @@ def make_jobs(nshapes, seed):
                 continue
             dtype = rnd.choice(["fp32", "fp64"])
             opts = (["--3d"] if ndim == 3 else []) + ["--dtype", dtype] + opt
-            jobs.append((stc, ndim, step, h * step, dims, dtype, opts, rnd.randint(2, 5), rnd.choice([1, 2])))
+            alone = None
+            if "--sn" in opts and rnd.random() < 0.4:      # whole-slab launches of an every = 2 pair on their own kernel: one stream block per tile
+                alone = list(opts); alone[alone.index("--sn") + 1] = "400"
+            jobs.append((stc, ndim, step, h * step, dims, dtype, opts, rnd.randint(2, 8), rnd.choice([1, 2]), alone))
     return jobs
 
 
 def build(job):
-    stc, ndim, step, halo, dims, dtype, opts, world, every = job
+    stc, ndim, step, halo, dims, dtype, opts, world, every, alone = job
     try:
         drs.Kernel(opts + [stc])
-        sw = HipSweep(stc, opts, CACHE)
+        sw = HipSweep(stc, opts, CACHE, alone_opts=alone)
         cut = dims[0] if ndim == 3 else dims[1]
         for r in range(world):
             sw.prebuild(SlabPlan(cut, halo, world, r, every))
@@ -104,7 +108,7 @@ class _Mailbox:
 
 
 def check(job, torch):
-    stc, ndim, step, halo, dims, dtype, opts, world, every = job
+    stc, ndim, step, halo, dims, dtype, opts, world, every, alone = job
     full = drs.Kernel(opts + [stc])
     L, M, N = dims
     shape = (L, M, N) if ndim == 3 else (M, N)
@@ -117,7 +121,7 @@ def check(job, torch):
     torch.cuda.synchronize()
     hub = _Hub()
     dev = torch.device("cuda", 0)
-    sweep = HipSweep(stc, opts, CACHE)
+    sweep = HipSweep(stc, opts, CACHE, alone_opts=alone)
     runs = [SlabRun(torch, _Mailbox(hub, r, torch), shape, halo, step, iterations, r, world, sweep, dev, tdt, every=every) for r in range(world)]
     for r in runs:
         r.load_global(lambda lo, hi: A0[lo:hi])
@@ -170,8 +174,8 @@ def main():
             print("ERROR", " ".join(str(e).split())[:300], flush=True)
         if not good:
             bad += 1
-            print("MISMATCH world %d every %d" % (job[7], job[8]), " ".join(job[6]), os.path.basename(job[0]), flush=True)
-    print("%d slab runs (worlds 2-5, both exchange modes) checked against the single-domain kernel: %d MISMATCHES" % (len(ok), bad))
+            print("MISMATCH world %d every %d%s" % (job[7], job[8], " alone-kernels" if job[9] else ""), " ".join(job[6]), os.path.basename(job[0]), flush=True)
+    print("%d slab runs (worlds 2-8, both exchange modes) checked against the single-domain kernel: %d MISMATCHES" % (len(ok), bad))
     sys.exit(1 if bad else 0)
 
 
