@@ -127,3 +127,17 @@ def test_c1_reference_cpu_path_plumbing():
     A2, B2 = A0.copy(), np.zeros_like(A0)
     oracle.run(spec, A2, B2, contract=0)
     assert oracle.check(spec, A, A2)["max_rel"] <= 2e-6
+
+
+def test_random_shapes_against_the_reference_binary():
+    """Where the reference's sources are present (the authoring container; oracle/Makefile builds its generator from them
+    where they lie), a small slice of oracle/fuzz_vs_reference.py: random stencil shapes through the reference binary and
+    through bin/drstencil (exit code, stdout, macros, gold term order and coefficient literals identical), and the oracle
+    against the reference-emitted gold statement, bit for bit.  profiles/r02_fuzz_vs_reference.txt is the 3 000-shape run."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if not (os.path.exists(os.path.join(root, "oracle", "_ref", "drstencil_ref")) and os.path.isdir("/root/reference")):
+        pytest.skip("the reference is not present on this box")
+    p = subprocess.run([sys.executable, os.path.join(root, "oracle", "fuzz_vs_reference.py"), "40", "7", "8"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
+    assert p.returncode == 0 and " 0 DIFFERENCES" in p.stdout, p.stdout[-2000:]
+    assert "bit for bit on 8 of 8 sampled cases" in p.stdout, p.stdout[-600:]
