@@ -9,7 +9,7 @@
 #include <stdlib.h>
 typedef float v4 __attribute__((ext_vector_type(4)));
 
-template <int LX, int RY, int DEPTH, bool SYNC = false>
+template <int LX, int RY, int DEPTH, bool SYNC = false, int LDSKB = 0, bool STORE_FIRST = false>
 __global__ __launch_bounds__(512) void tile_copy(const float* __restrict__ in, float* __restrict__ out, int N, int M, int L, long pitch, long plane, int sn, int band)
 {
     constexpr int LY = 512 / LX;            // rows of lanes
@@ -25,6 +25,11 @@ __global__ __launch_bounds__(512) void tile_copy(const float* __restrict__ in, f
     const int k0 = zb * sn, k1 = min(k0 + sn, L);
     const float* pin = in + (long)k0 * plane + off;
     float* pout = out + (long)k0 * plane + off;
+    if (LDSKB > 0) {                        // occupancy limiter: LDSKB KiB of LDS per workgroup (160 KiB per CU)
+        __shared__ float pad[LDSKB > 0 ? LDSKB * 256 : 1];
+        if (pitch < 0) pad[threadIdx.x] = 1.0f;
+        if (pitch < -1) pout[0] = pad[(threadIdx.x + 1) % 512];
+    }
     v4 buf[DEPTH][RY];
 #pragma unroll
     for (int d = 0; d < DEPTH; d++)
@@ -39,27 +44,31 @@ __global__ __launch_bounds__(512) void tile_copy(const float* __restrict__ in, f
             v4 cur[RY];
 #pragma unroll
             for (int r = 0; r < RY; r++) cur[r] = buf[d][r];
+            if (STORE_FIRST)
+#pragma unroll
+                for (int r = 0; r < RY; r++) __builtin_nontemporal_store(cur[r], (v4*)(pout + (long)(k - k0 + d) * plane + (long)r * pitch));
             if (k + d + DEPTH < k1)
 #pragma unroll
                 for (int r = 0; r < RY; r++) buf[d][r] = *(const v4*)(pin + (long)(k - k0 + d + DEPTH) * plane + (long)r * pitch);
+            if (!STORE_FIRST)
 #pragma unroll
-            for (int r = 0; r < RY; r++) __builtin_nontemporal_store(cur[r], (v4*)(pout + (long)(k - k0 + d) * plane + (long)r * pitch));
+                for (int r = 0; r < RY; r++) __builtin_nontemporal_store(cur[r], (v4*)(pout + (long)(k - k0 + d) * plane + (long)r * pitch));
         }
     }
 }
 
-template <int LX, int RY, int DEPTH, bool SYNC = false>
+template <int LX, int RY, int DEPTH, bool SYNC = false, int LDSKB = 0, bool STORE_FIRST = false>
 static void run(const char* name, const float* a, float* b, int N, int M, int L, long pitch, int sn, int band)
 {
     constexpr int TW = LX * 4, TH = (512 / LX) * RY;
     const long plane = pitch * M;
     const int grid = (N / TW) * (M / TH) * ((L + sn - 1) / sn);
     hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
-    for (int w = 0; w < 3; w++) tile_copy<LX, RY, DEPTH, SYNC><<<grid, 512>>>(a, b, N, M, L, pitch, plane, sn, band);
+    for (int w = 0; w < 3; w++) tile_copy<LX, RY, DEPTH, SYNC, LDSKB, STORE_FIRST><<<grid, 512>>>(a, b, N, M, L, pitch, plane, sn, band);
     float best = 1e9f, sum = 0;
     for (int r = 0; r < 7; r++) {
         (void)hipEventRecord(e0, 0);
-        for (int i = 0; i < 5; i++) tile_copy<LX, RY, DEPTH, SYNC><<<grid, 512>>>(a, b, N, M, L, pitch, plane, sn, band);
+        for (int i = 0; i < 5; i++) tile_copy<LX, RY, DEPTH, SYNC, LDSKB, STORE_FIRST><<<grid, 512>>>(a, b, N, M, L, pitch, plane, sn, band);
         (void)hipEventRecord(e1, 0); (void)hipEventSynchronize(e1);
         float ms; (void)hipEventElapsedTime(&ms, e0, e1); ms /= 5; sum += ms; if (ms < best) best = ms;
     }
@@ -77,12 +86,27 @@ int main()
     float *a, *b;
     if (hipMalloc(&a, elems * 4) != hipSuccess || hipMalloc(&b, elems * 4) != hipSuccess) { printf("hipMalloc failed\n"); return 1; }
     (void)hipMemset(a, 0, elems * 4); (void)hipMemset(b, 0, elems * 4);
-    for (int padded = 0; padded < 2; padded++) {
+    for (int padded = 0; padded < (getenv("TILEBENCH_PADDED") ? 2 : 1); padded++) {
         const long pitch = N + (padded ? pad : 0);
         printf("---- row pitch %ld bytes%s\n", pitch * 4, padded ? " (padded by 256 bytes: NOT the reference's layout)" : " (dense: the reference's layout)");
         run<32, 2, 3>("128-column tiles (the fused kernel's shape)", a, b, N, M, L, pitch, 32, 1);
         run<32, 2, 3, true>("128-column tiles, barrier per plane", a, b, N, M, L, pitch, 32, 1);
         run<32, 2, 3, true>("128-column tiles, barrier, 8-plane blocks", a, b, N, M, L, pitch, 8, 1);
+        run<32, 2, 3, true, 100>("128-col, barrier, 1 workgroup per CU", a, b, N, M, L, pitch, 32, 1);
+        run<32, 2, 3, true, 60>("128-col, barrier, 2 workgroups per CU", a, b, N, M, L, pitch, 32, 1);
+        run<32, 2, 3, true, 100, true>("128-col, barrier, 1 wg/CU, stores first", a, b, N, M, L, pitch, 32, 1);
+        run<32, 2, 3, true, 0, true>("128-col, barrier, stores first", a, b, N, M, L, pitch, 32, 1);
+        run<32, 2, 1, true>("128-col, barrier, 1 plane in flight", a, b, N, M, L, pitch, 32, 1);
+        run<32, 2, 5, true>("128-col, barrier, 5 planes in flight", a, b, N, M, L, pitch, 32, 1);
+        run<32, 4, 2, true>("128 x 64 tiles, barrier", a, b, N, M, L, pitch, 32, 1);
+        run<32, 1, 3, true>("128 x 16 tiles, barrier", a, b, N, M, L, pitch, 32, 1);
+        run<64, 2, 3, true>("256 x 16 tiles, barrier", a, b, N, M, L, pitch, 32, 1);
+        run<64, 4, 3, true>("256 x 32 tiles, barrier", a, b, N, M, L, pitch, 32, 1);
+        run<128, 4, 3, true>("512 x 16 tiles, barrier", a, b, N, M, L, pitch, 32, 1);
+        run<256, 4, 3, true>("full rows x 8, barrier, 32-plane blocks", a, b, N, M, L, pitch, 32, 1);
+        run<256, 4, 3, true, 100>("full rows x 8, barrier, 1 wg/CU, sn 4", a, b, N, M, L, pitch, 4, 1);
+        run<256, 4, 1, true, 100>("full rows x 8, barrier, 1 wg/CU, depth 1", a, b, N, M, L, pitch, 4, 1);
+        run<256, 4, 1, true, 60>("full rows x 8, barrier, 2 wg/CU, depth 1", a, b, N, M, L, pitch, 4, 1);
         run<32, 2, 3>("128-column tiles, no band map", a, b, N, M, L, pitch, 32, 0);
         run<32, 2, 1>("128-column tiles, 1 plane in flight", a, b, N, M, L, pitch, 32, 1);
         run<32, 2, 3>("128-column tiles, 8-plane blocks", a, b, N, M, L, pitch, 8, 1);
