@@ -16,9 +16,12 @@ __global__ __launch_bounds__(512) void tile_copy(const float* __restrict__ in, f
     constexpr int TW = LX * 4, TH = LY * RY;
     const int tiles_x = N / TW, tiles_y = M / TH, tiles = tiles_x * tiles_y;
     // XCD band map: workgroup ids round-robin over 8 XCDs; give every XCD a contiguous band of tiles
-    int wg = blockIdx.x;
-    if (band) { const int per = gridDim.x / 8; wg = (wg % 8) * per + wg / 8; }
-    const int zb = wg / tiles, t = wg % tiles;
+    // band = 1: every XCD (workgroup id % 8) takes a contiguous eighth of the (stream block, tile) list
+    // band = 2: the generator's --xcd-remap 2: every XCD owns a fixed band of the x-y tiles of EVERY stream block and all XCDs walk the
+    //           stream blocks together (one compact front through memory)
+    int wg = blockIdx.x, zb, t;
+    if (band == 2) { const int xcd = wg % 8, slot = wg / 8, per = tiles / 8; t = xcd * per + slot % per; zb = slot / per; }
+    else { if (band) { const int per = gridDim.x / 8; wg = (wg % 8) * per + wg / 8; } zb = wg / tiles; t = wg % tiles; }
     const int tx = t % tiles_x, ty = t / tiles_x;
     const int lx = threadIdx.x % LX, ly = threadIdx.x / LX;
     const long off = (long)(ty * TH + ly * RY) * pitch + (long)tx * TW + lx * 4;
@@ -89,6 +92,16 @@ int main()
     for (int padded = 0; padded < (getenv("TILEBENCH_PADDED") ? 2 : 1); padded++) {
         const long pitch = N + (padded ? pad : 0);
         printf("---- row pitch %ld bytes%s\n", pitch * 4, padded ? " (padded by 256 bytes: NOT the reference's layout)" : " (dense: the reference's layout)");
+        run<32, 2, 3, true>("128 x 32, barrier, generator's band map", a, b, N, M, L, pitch, 32, 2);
+        run<32, 2, 3, true>("128 x 32, barrier, band map, 8-plane blocks", a, b, N, M, L, pitch, 8, 2);
+        run<32, 2, 3, true, 100>("128 x 32, barrier, band map, 1 wg/CU", a, b, N, M, L, pitch, 32, 2);
+        run<32, 2, 3, true, 60>("128 x 32, barrier, band map, 2 wg/CU", a, b, N, M, L, pitch, 32, 2);
+        run<32, 2, 3, false>("128 x 32, no barrier, band map", a, b, N, M, L, pitch, 32, 2);
+        run<64, 4, 3, true>("256 x 32, barrier, band map", a, b, N, M, L, pitch, 32, 2);
+        run<256, 4, 1, true, 100>("full rows x 8, barrier, band map, 1 wg/CU", a, b, N, M, L, pitch, 4, 2);
+        run<256, 4, 1, true, 60>("full rows x 8, barrier, band map, 2 wg/CU", a, b, N, M, L, pitch, 4, 2);
+        run<256, 4, 1, false, 60>("full rows x 8, no barrier, band map, 2 wg/CU", a, b, N, M, L, pitch, 4, 2);
+        run<256, 4, 1, true>("full rows x 8, barrier, band map", a, b, N, M, L, pitch, 4, 2);
         run<32, 2, 3>("128-column tiles (the fused kernel's shape)", a, b, N, M, L, pitch, 32, 1);
         run<32, 2, 3, true>("128-column tiles, barrier per plane", a, b, N, M, L, pitch, 32, 1);
         run<32, 2, 3, true>("128-column tiles, barrier, 8-plane blocks", a, b, N, M, L, pitch, 8, 1);
