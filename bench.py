@@ -407,6 +407,15 @@ def main(argv=None):
     if not args.prebuild_only and not rehearse and world != args.gpus:       # decided before anything touches the GPU
         raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
 
+    # stdout carries exactly ONE line, the result: RCCL prints a version banner on stdout when its first communicator comes up
+    # (rank 0, five lines), and libraries may print more -- so from here on file descriptor 1 is stderr, and the JSON line goes
+    # to the saved descriptor at the end
+    result_fd = 1
+    if not args.prebuild_only:
+        sys.stdout.flush()
+        result_fd = os.dup(1)
+        os.dup2(2, 1)
+
     import drstencil_amd as drs
 
     if not os.path.exists(drs.LIB_PATH):
@@ -625,7 +634,8 @@ def main(argv=None):
                 out["verified"] = bool(out["verified"] and oracle_check["ok"])
         else:
             out["cpu_baseline"] = None
-        print(json.dumps(out), flush=True)
+        sys.stdout.flush()
+        os.write(result_fd, (json.dumps(out) + "\n").encode())
     if dist is not None:
         dist.destroy_process_group()
 
