@@ -150,6 +150,25 @@ def _run_c_host(drs):
         f.write(text)
 
 
+def _run_bench_rehearsal():
+    """bench.py's N > 1 branch as a child process (rank 1 of 4 on this one GPU, self-neighbour exchange through a real RCCL
+    process group), before this process touches HIP: the test reads what arrived on its stdout."""
+    import subprocess
+    out = os.path.join(ROOT, "drstencil_amd", "_kcache", "bench_rehearsal")
+    os.makedirs(out, exist_ok=True)
+    env = dict(os.environ, DRS_REHEARSE="1/4", MASTER_ADDR="127.0.0.1")
+    try:
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"],
+                           env=env, capture_output=True, text=True, timeout=300)
+        stdout, text = r.stdout, "[rc=%d]\n%s" % (r.returncode, r.stderr[-1500:])
+    except Exception as e:
+        stdout, text = "", "[exception] %r" % (e,)
+    with open(os.path.join(out, "stdout.txt"), "w") as f:
+        f.write(stdout)
+    with open(os.path.join(out, "stderr.txt"), "w") as f:
+        f.write(text)
+
+
 def pytest_sessionstart(session):
     """GPU sessions: make sure every kernel the gpu tests use is built (normally a cache hit:
     __graft_entry__.build() prebuilds them) BEFORE anything initialises HIP -- a process that
@@ -167,6 +186,7 @@ def pytest_sessionstart(session):
     _run_tuner_smoke()
     _run_reference_flow(drs)
     _run_c_host(drs)
+    _run_bench_rehearsal()
     from gpu_cases import all_build_args, golden_args
     from helpers import golden_cases, load_golden
     jobs = all_build_args()

@@ -357,6 +357,21 @@ def test_sampled_parity_fuzz(torch_cuda):
     assert checked >= 30 and checked + refused == len(fuzz_sample_jobs())
 
 
+def test_bench_stdout_is_one_json_line_with_rccl_up():
+    """bench.py's multi-GPU branch rehearsed at session start (rank 1 of 4 on this GPU, a real RCCL process group): its stdout
+    is exactly ONE line, the result -- RCCL's version banner, which rank 0 prints on stdout when the first communicator comes
+    up, must not precede it (the driver parses that line)."""
+    d = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "drstencil_amd", "_kcache", "bench_rehearsal")
+    out, err = open(os.path.join(d, "stdout.txt")).read(), open(os.path.join(d, "stderr.txt")).read()
+    assert err.startswith("[rc=0]"), err[-1500:]
+    lines = out.splitlines()
+    assert len(lines) == 1, out[:600]
+    rec = json.loads(lines[0])
+    assert rec["unit"] == "GStencil/s" and rec["value"] > 0 and rec["steps"] == 2 and rec["higher_is_better"] is True
+    assert "REHEARSAL" in rec["config"]["parallelism"] and "RCCL send/recv" in rec["config"]["parallelism"]
+    assert rec["roofline"]["bound"] == "hbm" and rec["config"]["exchange_calibration"]["chosen_every"] in (1, 2)
+
+
 def test_c_host_through_the_abi():
     """A plain-C host (tests/native/capi_gpu_host.c = the INTEGRATION.md example) built with gcc, run at session start:
     drs_kernel_build, hipMalloc'ed buffers, drs_kernel_run_timed, the gold kernel through drs_kernel_run, drs_check_error --
