@@ -39,13 +39,18 @@ WORKLOADS = {
     "c3f64": dict(stc=os.path.join(CFG, "c3_3d7pt_star_512.stc"), ndim=3, dtype="fp64", name="3d7pt_star 512^3 fp64 (reference precision and size), iterations 4"),
     "c4f64": dict(stc=os.path.join(CFG, "c4_3d7pt_star_1024.stc"), ndim=3, dtype="fp64", name="3d7pt_star 1024^3 fp64 (reference precision), iterations 4"),
     # the reference's other shipped benchmark directories as they stand (benchmarks/<name>/<name>.stc: 8192^2 / 512^3, fp64, iterations 4);
-    # 3d7pt_star is c3f64 above; 2d9pt_cross is left out: its spec's `iteratioins` typo leaves Iterations 0
+    # 3d7pt_star is c3f64 above.  2d9pt_cross: its spec's `iteratioins` typo (benchmarks/2d9pt_cross/2d9pt_cross.stc:4) leaves Iterations
+    # unset in the reference (its emitted program times ZERO launches), so the workload runs the spec as shipped -- the
+    # generated kernel says Iterations 0 like the reference's -- with the iteration count the other seven specs use given explicitly
+    # to drs_kernel_run (`iterations`: 4)
     "s_2d5pt_star": dict(stc=os.path.join(ROOT, "benchmarks", "2d5pt_star", "2d5pt_star.stc"), ndim=2, dtype="fp64", name="2d5pt_star 8192^2 fp64 (shipped spec), iterations 4"),
     "s_2d5pt_cross": dict(stc=os.path.join(ROOT, "benchmarks", "2d5pt_cross", "2d5pt_cross.stc"), ndim=2, dtype="fp64", name="2d5pt_cross 8192^2 fp64 (shipped spec), iterations 4"),
     "s_2d9pt_box": dict(stc=os.path.join(ROOT, "benchmarks", "2d9pt_box", "2d9pt_box.stc"), ndim=2, dtype="fp64", name="2d9pt_box 8192^2 fp64 (shipped spec), iterations 4"),
     "s_2d9pt_star": dict(stc=os.path.join(ROOT, "benchmarks", "2d9pt_star", "2d9pt_star.stc"), ndim=2, dtype="fp64", name="2d9pt_star 8192^2 fp64 (shipped spec), iterations 4"),
     "s_2d25pt_box": dict(stc=os.path.join(ROOT, "benchmarks", "2d25pt_box", "2d25pt_box.stc"), ndim=2, dtype="fp64", name="2d25pt_box 8192^2 fp64 (shipped spec), iterations 4"),
     "s_3d9pt_cross": dict(stc=os.path.join(ROOT, "benchmarks", "3d9pt_cross", "3d9pt_cross.stc"), ndim=3, dtype="fp64", name="3d9pt_cross 512^3 fp64 (shipped spec), iterations 4"),
+    "s_2d9pt_cross": dict(stc=os.path.join(ROOT, "benchmarks", "2d9pt_cross", "2d9pt_cross.stc"), ndim=2, dtype="fp64", iterations=4,
+                          name="2d9pt_cross 8192^2 fp64 (shipped spec: `iteratioins` typo, Iterations unset), run with iterations 4 given explicitly"),
 }
 # tuned generator options per workload (found with drstencil_amd/tuner; logs under profiles/).
 # Headline for the 3D workloads: two time steps per launch with the reference's own --step 2 arithmetic
@@ -78,6 +83,8 @@ TUNED = {
     "s_2d5pt_star": ["--dtype", "fp64", "--step", "2", "--bx", "128", "--by", "4", "--block-merge-x", "2", "--block-merge-y", "2", "--xcd-remap", "0"],
     "s_2d5pt_cross": ["--dtype", "fp64", "--step", "2", "--dist", "2", "--bx", "64", "--by", "4", "--block-merge-x", "2", "--block-merge-y", "4", "--xcd-remap", "0"],
     "s_2d9pt_box": ["--dtype", "fp64", "--step", "2", "--bx", "64", "--by", "4", "--block-merge-x", "2", "--block-merge-y", "4", "--xcd-remap", "0"],
+    # 2d9pt_cross (diagonal cross of order 2; the reference's tuner sweeps it at --step 2 --dist 2, benchmarks/2d9pt_cross/tuning.py:127): fused, bit-exact
+    "s_2d9pt_cross": ["--dtype", "fp64", "--step", "2", "--dist", "2", "--bx", "64", "--by", "4", "--block-merge-x", "2", "--block-merge-y", "4", "--xcd-remap", "0"],
     # the wide stencils (order 2 / 35 fused taps) are fastest as on-chip temporal pipelines; in fp64 those stay within 1e-12 of the fused
     # arithmetic (measured 1.7e-15), the bar the tests and bench.py's verification hold fp64 temporal kernels to
     "s_2d9pt_star": ["--dtype", "fp64", "--step", "2", "--dist", "4", "--temporal", "1", "--bx", "66", "--by", "15", "--block-merge-x", "2", "--block-merge-y", "2", "--xcd-remap", "0"],
@@ -161,7 +168,7 @@ def pmc_traffic(workload, option_string):
         return None, "no PMC passes committed for [%s][%s] in %s" % (workload, option_string, path)
 
 
-def cpu_baseline(workload, step, budget_s=15.0, host_slab=None, gpu_first_launch=None, temporal=False):
+def cpu_baseline(workload, step, budget_s=4.0, host_slab=None, gpu_first_launch=None, temporal=False):
     """The CPU leg (the only place bench.py touches oracle/): the oracle (port) timed on the host cores on a bounded z/y-slab
     sample of the workload -- the first slices of the very array the GPU loop started from (host_slab), or seeded random
     numbers of the same shape -- and, as the checker, one oracle sweep of the first 2*Halo+12 slices against what the timed GPU
@@ -203,12 +210,14 @@ def cpu_baseline(workload, step, budget_s=15.0, host_slab=None, gpu_first_launch
         Ms = min(M, 4096)
         spec.set_dims(1, Ms, N)
         sample = "SAMPLE: %d x %d y-slab of the %d x %d grid" % (Ms, N, M, N)
+    # both arrays are first touched by the OpenMP team that sweeps them (the GPU box's host has two sockets), then filled
+    A = oracle.empty_first_touched(spec, dt)
+    B = oracle.empty_first_touched(spec, dt)
     if host_slab is not None and tuple(host_slab.shape) == tuple(spec.shape):
-        A = np.ascontiguousarray(host_slab, dtype=dt)
+        oracle.copy_into(spec, A, np.ascontiguousarray(host_slab, dtype=dt))
         sample += " (the GPU run's own input)"
     else:
-        A = np.random.default_rng(1).random(spec.shape, dtype=dt)
-    B = np.zeros_like(A)
+        oracle.copy_into(spec, A, np.random.default_rng(1).random(spec.shape, dtype=dt))
     h = spec.halo
     interior = 1
     for d in spec.shape:
@@ -224,8 +233,9 @@ def cpu_baseline(workload, step, budget_s=15.0, host_slab=None, gpu_first_launch
         if el > budget_s or sweeps >= 400:
             break
     gst = sweeps * step * interior / el / 1e9
-    return dict(value=gst, unit="GStencil/s", cores=oracle.threads(), kind="port",
-                sample="%s, %d sweeps in %.1f s (OpenMP, %d threads)" % (sample, sweeps, el, oracle.threads())), check
+    return dict(value=gst, unit="GStencil/s", cores=oracle.threads(), kind="port", isa=oracle.isa(),
+                sample="%s, %d sweeps in %.1f s (OpenMP, %d threads, %s clone of the sweep, arrays first-touched by the team)"
+                       % (sample, sweeps, el, oracle.threads(), oracle.isa())), check
 
 
 def verify_timed_kernel(torch, kern, workload, A, B, temporal):
@@ -338,6 +348,7 @@ def parse_args(argv=None):
     ap.add_argument("--headline-only", action="store_true", help="skip the side measurements (profiling runs: one dr_ kernel in the trace)")
     ap.add_argument("--no-verify", action="store_true", help="skip the post-loop comparison of the timed kernel with the gold kernel and the oracle")
     ap.add_argument("--n1-value", type=float, default=None, help="N > 1: the N = 1 value of the same workload; the line then carries value / (N * n1) as efficiency_vs_n1")
+    ap.add_argument("--rank-timeout", type=float, default=900.0, help="N > 1 as a plain command: wall-clock limit for the rank processes this launcher starts (then terminate, kill, exit 124)")
     ap.add_argument("--prebuild-only", action="store_true", help="build (or find cached) every kernel the run needs for all --gpus ranks, then exit; no GPU is touched")
     return ap.parse_args(argv)
 
@@ -374,6 +385,9 @@ def spawn_ranks(args, argv):
         port = sk.getsockname()[1]
     procs = [subprocess.Popen(child_command(argv), env=rank_env(r, n, port), stdout=subprocess.PIPE if r == 0 else sys.stderr, text=(r == 0)) for r in range(n)]
     worst = 0
+    # a rank that hangs (RCCL rendezvous, a collective whose partner never arrives) would keep this loop alive for ever: after
+    # --rank-timeout seconds of wall clock the ranks are terminated, then killed, and the launcher exits 124
+    deadline = time.time() + max(1.0, args.rank_timeout)
     try:
         alive = set(range(n))
         while alive:
@@ -386,6 +400,15 @@ def spawn_ranks(args, argv):
                 if code != 0:            # a rank died: the others would wait for it in RCCL for ever
                     for q in alive:
                         procs[q].terminate()
+            if alive and time.time() > deadline:
+                print("bench.py: rank(s) %s still running after %.0f s: terminating them" % (sorted(alive), args.rank_timeout), file=sys.stderr)
+                for q in alive:
+                    procs[q].terminate()
+                t_kill = time.time() + 10.0
+                while time.time() < t_kill and any(procs[q].poll() is None for q in alive):
+                    time.sleep(0.1)
+                worst = 124
+                break
             time.sleep(0.05)
     finally:
         for p in procs:
@@ -442,6 +465,8 @@ def main(argv=None):
     spec = drs.Spec(w["stc"], w["ndim"], int(opts[opts.index("--step") + 1]) if "--step" in opts else 1)
     L, M, N = spec.dims
     H, step, iters = spec.halo, spec.step, spec.iterations
+    if w.get("iterations") and iters <= 0:      # a spec without a (readable) iteration count: the workload names one
+        iters = int(w["iterations"])
     weak = args.scaling == "weak" and pworld > 1
     if weak:       # the outermost dim grows with the number of ranks: fixed work per GPU
         if w["ndim"] == 3:
@@ -489,7 +514,7 @@ def main(argv=None):
 
     tdt = torch.float32 if w["dtype"] == "fp32" else torch.float64
     esz = 4 if w["dtype"] == "fp32" else 8
-    launches_per_step = spec.launches
+    launches_per_step = 2 * (-(-iters // (2 * step))) if iters > 0 else 0      # codegen.hpp:581-584 (== spec.launches when the spec names the count)
     interior = (M - 2 * H) * (N - 2 * H) * ((L - 2 * H) if w["ndim"] == 3 else 1)
     npoints = M * N * (L if w["ndim"] == 3 else 1)
 
@@ -503,14 +528,14 @@ def main(argv=None):
         B = torch.zeros_like(A)
         stream = torch.cuda.current_stream(dev)
         for _ in range(args.warmup):
-            kern.run(A.data_ptr(), B.data_ptr(), stream=stream.cuda_stream)
+            kern.run(A.data_ptr(), B.data_ptr(), iterations=iters, stream=stream.cuda_stream)
         torch.cuda.synchronize()
         # a few milliseconds of launches do not bring the GPU to its steady clocks (C3: 221 us per launch right after 2 ms of
         # warm-up, 193 us from then on -- scripts/c3_loop_probe.py): keep running untimed steps until MIN_WARM_S have gone by
         tw = time.perf_counter()
         while args.warmup > 0 and time.perf_counter() - tw < MIN_WARM_S:
             for _ in range(8):
-                kern.run(A.data_ptr(), B.data_ptr(), stream=stream.cuda_stream)
+                kern.run(A.data_ptr(), B.data_ptr(), iterations=iters, stream=stream.cuda_stream)
                 warm_extra += 1
             torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -518,7 +543,7 @@ def main(argv=None):
         e0.record(stream)
         n = 0
         for _ in range(args.steps):
-            n += kern.run(A.data_ptr(), B.data_ptr(), stream=stream.cuda_stream)
+            n += kern.run(A.data_ptr(), B.data_ptr(), iterations=iters, stream=stream.cuda_stream)
         e1.record(stream)
         torch.cuda.synchronize()
         el = time.perf_counter() - t0
@@ -530,9 +555,18 @@ def main(argv=None):
         def side(k, o, iters):
             # side measurement on the same grid (reference protocol: warm-up launches, then the timed
             # ping-pong loop bracketed by HIP events)
-            n1, ms1 = k.run_timed(A.data_ptr(), B.data_ptr(), iterations=iters, warmup=4, stream=stream.cuda_stream)
+            hz = k.info.get("tolerance_horizon_iterations", -1)
+            if k.info.get("arithmetic") == "reassociated" and not k.info.get("temporal_forced") and 0 < hz < iters:
+                # a temporal pipeline keeps the tolerance up to its horizon only (drs_kernel_run refuses more): timed in loops of that length
+                n1, ms1 = 0, 0.0
+                for rep in range(-(-iters // hz)):
+                    n_, ms_ = k.run_timed(A.data_ptr(), B.data_ptr(), iterations=hz, warmup=4 if rep == 0 else 0, stream=stream.cuda_stream)
+                    n1, ms1 = n1 + n_, ms1 + ms_
+            else:
+                n1, ms1 = k.run_timed(A.data_ptr(), B.data_ptr(), iterations=iters, warmup=4, stream=stream.cuda_stream)
             by = k.bytes_per_launch()
-            return {"generator_options": " ".join(o), "GStencil_per_s": k.updates_per_launch() * n1 / (ms1 * 1e-3) / 1e9,
+            return {"generator_options": " ".join(o), "arithmetic": k.info.get("arithmetic"), "tolerance_horizon_iterations": k.info.get("tolerance_horizon_iterations"),
+                    "GStencil_per_s": k.updates_per_launch() * n1 / (ms1 * 1e-3) / 1e9,
                     "avg_launch_ms": ms1 / n1, "achieved_GBps": by * n1 / (ms1 * 1e-3) / 1e9,
                     "roofline_frac": by * n1 / (ms1 * 1e-3) / 1e9 / HBM_PEAK_GBS}
         step1 = side(kern1, STEP1[args.workload], 16) if kern1 is not None else None
@@ -638,6 +672,10 @@ def main(argv=None):
         os.write(result_fd, (json.dumps(out) + "\n").encode())
     if dist is not None:
         dist.destroy_process_group()
+    # a number from a kernel whose result is wrong is not a measurement: the line says "verified": false AND the exit code says so
+    # (every rank holds the same AND-ed verdict of an N > 1 run; at N = 1 rank 0 folds the oracle's verdict in above)
+    if (out["verified"] if rank == 0 else verified) is False:
+        raise SystemExit(3)
 
 
 if __name__ == "__main__":

@@ -161,6 +161,11 @@ class KernelBuildError(RuntimeError):
     pass
 
 
+class ToleranceHorizonExceeded(RuntimeError):
+    """drs_kernel_run / drs_kernel_run_timed returned -3: a temporal (reassociated) kernel was asked for more iterations than it keeps
+    the 1e-6 (fp32) / 1e-12 (fp64) tolerance for (include/drstencil_amd.h)."""
+
+
 class Kernel:
     """A generated kernel: drstencil options -> HIP source -> hipcc (gfx950) -> loaded.
 
@@ -199,6 +204,8 @@ class Kernel:
         """The reference's ping-pong loop (codegen.hpp:581-584); result ends in A."""
         it = self.info["iterations"] if iterations is None else iterations
         n = lib().drs_kernel_run(self.h, d_a, d_b, it, 1 if gold else 0, stream)
+        if n == -3:
+            raise ToleranceHorizonExceeded(self._horizon_message(it))
         if n < 0:
             raise RuntimeError("HIP error in drs_kernel_run")
         return n
@@ -208,9 +215,15 @@ class Kernel:
         it = self.info["iterations"] if iterations is None else iterations
         ms = ctypes.c_float()
         n = lib().drs_kernel_run_timed(self.h, d_a, d_b, it, warmup, stream, ctypes.byref(ms))
+        if n == -3:
+            raise ToleranceHorizonExceeded(self._horizon_message(it))
         if n < 0:
             raise RuntimeError("HIP error in drs_kernel_run_timed")
         return n, ms.value
+
+    def _horizon_message(self, it):
+        return ("%d iterations exceed the tolerance horizon (%d) of this reassociated (temporal) kernel: build the fused kernel, or pass "
+                "--temporal force" % (it, self.info.get("tolerance_horizon_iterations", -1)))
 
     # work / traffic model
     def updates_per_launch(self):

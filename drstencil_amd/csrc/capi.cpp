@@ -38,6 +38,10 @@ struct drs_kernel {
     std::string path;
     std::string resources;   // JSON: register / scratch / LDS use of dr_<name> as reported by the compiler
     int step = 1;
+    // temporal pipelines re-associate the reference's fused sum: within the tolerance (1e-6 relative fp32, 1e-12 fp64) up to
+    // `horizon` iterations only (planner.hpp: temporal_drift); -1 = gold order, any iteration count
+    int horizon = -1;
+    bool forced = false;     // --temporal force: the caller asked for the pipeline regardless
 };
 
 static char *dup_cstr(const std::string &s) {
@@ -338,6 +342,8 @@ drs_kernel *drs_kernel_build(int argc, const char *const *argv, const char *cach
     k->path = so;
     k->resources = resources;
     k->step = r.st.step;
+    k->horizon = r.plan.reassociated ? r.plan.horizon_iterations : -1;
+    k->forced = r.plan.temporal_forced;
     if (!k->launch || !k->launch_gold || !k->info) {
         if (log) *log = dup_cstr("plugin " + so + " lacks the drs_plugin_* entry points\n");
         dlclose(dl);
@@ -380,6 +386,9 @@ int drs_kernel_launch_gold(drs_kernel *k, const void *d_in, void *d_out, void *s
 
 int drs_kernel_run(drs_kernel *k, void *d_a, void *d_b, int iterations, int gold, void *stream) {
     auto fn = gold ? k->launch_gold : k->launch;
+    // a temporal pipeline is only offered where it keeps the tolerance: more iterations than its horizon need the fused kernel
+    // (or --temporal force, whose plugin says "temporal_forced" in drs_kernel_info)
+    if (!gold && k->horizon >= 0 && !k->forced && iterations > k->horizon) return -3;
     g_launched = true;
     int n = 0;
     for (int t = 0; t < iterations; t += 2 * k->step) {
@@ -392,6 +401,7 @@ int drs_kernel_run(drs_kernel *k, void *d_a, void *d_b, int iterations, int gold
 
 int drs_kernel_run_timed(drs_kernel *k, void *d_a, void *d_b, int iterations, int warmup, void *stream, float *ms) {
     hipStream_t s = (hipStream_t)stream;
+    if (k->horizon >= 0 && !k->forced && iterations > k->horizon) return -3;      // as drs_kernel_run, before anything is launched
     g_launched = true;
     for (int i = 0; i < warmup; i++)
         if (k->launch(d_a, d_b, s) != 0) return -1;

@@ -83,8 +83,11 @@ MI355X options:
                         plane's in-plane neighbours are kept in registers when that plane has at least --merge-forward
                         in-plane taps, else re-read from LDS when they are due;
                         window: every contributing plane resident, nothing carried.
---temporal <0|1>        With --step n > 1: run the one-step stencil n times on chip (temporal blocking,
-                        intermediate planes never leave the CU) instead of the fused stencil.
+--temporal <0|1|force>  With --step n > 1: run the one-step stencil n times on chip (temporal blocking,
+                        intermediate planes never leave the CU) instead of the fused stencil.  On-chip stages
+                        re-associate the fused sum: 1 emits them only where the estimated drift from the reference's
+                        fused arithmetic stays within 1e-6 relative (fp32; 1e-12 fp64) for the spec's `iterations`
+                        and emits the fused kernel otherwise (a note says so); force emits them regardless.
 --prefetch-depth <n>    With --prefetch: planes in flight ahead of the one being summed (n+1 register sets; default 3 (fp32) /
                         2 (fp64) for fused multi-step 3D kernels, else 1).
 --pair-launch <0|1>     Also emit dr2_<name>(in0, out0, in1, out1): the same sweep over two buffer pairs in one launch.
@@ -174,7 +177,13 @@ inline GenResult generate(const std::vector<std::string> &args /* argv[1..] */) 
         else if (a == "--pair-launch") { if (!int_opt(o.pair_launch, nullptr)) break; }
         else if (a == "--prefetch-auto") { if (!int_opt(o.prefetch_auto, nullptr)) break; }
         else if (a == "--prefetch-depth") { if (!int_opt(o.prefetch_depth, nullptr)) break; }
-        else if (a == "--temporal") { if (!int_opt(o.temporal, nullptr)) break; }
+        else if (a == "--temporal") {
+            std::string v;
+            if (!str_opt(v)) break;
+            if (v == "force") o.temporal = 2;
+            else if (v == "0" || v == "1" || v == "2") o.temporal = atoi(v.c_str());
+            else { res.messages += "Illegal input.\n"; res.exit_code = 255; return res; }
+        }
         else if (a == "--defer-stores") { if (!int_opt(o.defer_stores, nullptr)) break; }
         else if (a == "--drain") { if (!int_opt(o.drain, nullptr)) break; }
         else if (a == "--uniform-loads") { if (!int_opt(o.uniform_loads, nullptr)) break; }

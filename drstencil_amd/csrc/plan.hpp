@@ -90,7 +90,11 @@ struct GenOptions {
     int prefetch_depth = -1;     // planes in flight ahead of the one being summed (register sets = depth + 1); -1 auto:
                                  // 3 (fp32) / 2 (fp64) for fused multi-step 3D kernels (their wide halo leaves one resident workgroup per CU and
                                  // too few bytes in flight: 1.66 -> 1.56 ms on a slow-memory device, +1 % on a fast one), else 1
-    int temporal = 0;            // step > 1: apply the one-step stencil `step` times on chip instead of the fused stencil
+    int temporal = 0;            // step > 1: apply the one-step stencil `step` times on chip instead of the fused stencil (--temporal 1);
+                                 // on-chip stages re-associate the fused sum, so the generator only emits them where its a-priori drift
+                                 // estimate (planner.hpp: temporal_drift) stays within the dtype's bar (1e-6 relative fp32, 1e-12 fp64) for the
+                                 // spec's `iterations`, and emits the fused kernel (exact reference arithmetic) otherwise; 2 = --temporal force:
+                                 // emit the pipeline regardless (measurements, experiments; the plugin says so in drs_plugin_info)
     // Memory-path knobs of the streaming loop.  Defaults = the round-1 form, which the round-2 measurements could not beat
     // (profiles/r02_exp_r2a_vmcnt_pipeline.log, r02_exp_r2b_memory_path.log; DESIGN.md section 3 "vmcnt"): with guarded loads and
     // stores the compiler cannot count the vector-memory operations in flight and drains them (s_waitcnt vmcnt(0)) every plane;
@@ -157,6 +161,12 @@ struct KernelPlan {
     bool prefetch = false;
     int PD = 1;              // prefetch depth (planes in flight)
     bool dma = false;        // --stage dma: planes are staged by LDS-DMA into a per-lane-dense LDS image (emit_hip.hpp)
+    // temporal blocking and the tolerance (planner.hpp: temporal_drift): which arithmetic the kernel computes
+    bool reassociated = false;   // true: on-chip stages (equal to the reference's fused arithmetic up to rounding); false: gold order, bit-exact
+    bool temporal_forced = false;    // --temporal force: emitted although the estimate may exceed the bar
+    double drift_estimate = 0.0;     // predicted max relative distance from the fused arithmetic after the spec's iterations (0: gold order)
+    double drift_per_launch = 0.0;   // the same after one launch (grows ~ launches^0.62)
+    int horizon_iterations = -1;     // largest `iterations` for which the estimate stays within the bar (-1: unlimited, gold order)
     std::string error;       // non-empty: invalid configuration
     std::string note;        // non-empty: something the user asked for was not done (printed by the generator, kept in the banner)
 };

@@ -35,6 +35,37 @@ inline bool reference_invalid(const Stencil &st, const GenOptions &o, int mx, in
     return halo2 >= o.bx * mx && fi;
 }
 
+// A-priori estimate of how far a temporal pipeline (the one-step stencil applied `step` times on chip, every stage an FMA chain
+// in gold order) drifts from the reference's fused arithmetic (drstencil.hpp:262-282: ONE chain over the fused taps): the max
+// relative difference over the grid after `launches` launches of the ping-pong loop (codegen.hpp:581-584).
+//   * both sides are rounded evaluations of the same exact sum; their difference after one launch behaves like noise of
+//     u * sqrt(step * taps + fused taps) (u = unit roundoff: one rounding per FMA of either chain), scaled by the condition
+//     number of the sum for the harness's non-negative inputs, sum|c| / |sum c| (common.hpp:9-32: inputs in [0, 1]);
+//   * it grows like launches^0.62 (a random walk that the stencil's own averaging damps) and the MAX over n grid points sits
+//     sqrt(2 ln n) standard deviations out;
+//   * 0.178 is fitted to the MI355X measurements of round 2 (profiles/r02_temporal_margin.json: 3d7pt_star, 2 and 3 stages, 2 and
+//     50 / 34 launches on 96x80x264; scripts/parity_full.py at 1024^3) -- all six within 4 % -- and checked on the CPU against
+//     chained oracle sweeps for the shipped stencils and random shapes (tests/calibrate_temporal_drift.py,
+//     profiles/r03_temporal_drift_calibration.txt); 1.25 is the safety margin on top.
+// Returns the estimate for one launch; est(launches) = est(1) * launches^0.62.
+inline double temporal_drift_per_launch(const Stencil &st, bool fp32) {
+    const double u = fp32 ? 5.9604644775390625e-08 : 1.1102230246251565e-16;
+    double sabs = 0.0, ssum = 0.0;
+    for (auto &e : st.pts.v) { sabs += std::fabs(e.second); ssum += e.second; }
+    const double cond = std::fabs(ssum) > 1e-300 ? sabs / std::fabs(ssum) : 1e300;
+    double n = (double)std::max(1, st.M) * (double)std::max(1, st.N) * (st.ndim == 3 ? (double)std::max(1, st.L) : 1.0);
+    const double spread = std::sqrt(2.0 * std::log(std::max(16.0, n)));
+    return 1.25 * 0.178 * u * std::sqrt((double)st.step * (double)st.base.size() + (double)st.pts.size()) * spread * cond;
+}
+inline double temporal_bar(bool fp32) { return fp32 ? 1e-6 : 1e-12; }
+// largest `iterations` whose launches (2 * ceil(iterations / (2 * step))) keep the estimate within the bar; 0: not even one pair
+inline int temporal_horizon(double per_launch, bool fp32, int step) {
+    if (per_launch <= 0.0) return 1 << 30;
+    const double nmax = std::pow(temporal_bar(fp32) / per_launch, 1.0 / 0.62);
+    if (nmax >= 1e9) return 1 << 30;
+    return 2 * step * (int)(std::floor(nmax + 1e-9) / 2);
+}
+
 inline KernelPlan make_plan(const Stencil &st, const GenOptions &o_in, const std::string &name) {
     GenOptions o = o_in;
     KernelPlan p;
@@ -48,6 +79,41 @@ inline KernelPlan make_plan(const Stencil &st, const GenOptions &o_in, const std
     const bool stream2d = (st.ndim == 2 && o.streaming);
     p.has_s = (st.ndim == 3) || stream2d;
     p.has_y = (st.ndim == 3) || !stream2d;
+
+    // Temporal blocking applies the ONE-STEP stencil `step` times on chip.  It equals the
+    // reference's algebraically fused stencil (drstencil.hpp:262-282) up to rounding, provided
+    // the 6-digit rounding of the fused coefficients (drstencil.hpp:192) is a no-op; otherwise
+    // the fused single-pass kernel is emitted (exact reference arithmetic).
+    bool temporal = o.temporal && st.step > 1;
+    if (temporal)
+        for (auto &e : st.pts.v)
+            if (std::fabs(coef_rounded(e.second) - e.second) > 1e-12 * std::fabs(e.second)) temporal = false;
+    if (o.temporal && st.step > 1 && !temporal)
+        p.note = "--temporal 1 ignored: rounding the fused coefficients to 6 digits is not a no-op for this stencil, so on-chip "
+                 "stages would not equal the reference's fused arithmetic; the fused single-pass kernel is emitted instead";
+    // ... and provided the re-association stays within the tolerance for the spec's iteration count (--temporal force overrides)
+    if (temporal) {
+        p.drift_per_launch = temporal_drift_per_launch(st, p.fp32);
+        const int launches = st.launches();
+        p.drift_estimate = p.drift_per_launch * std::pow((double)std::max(1, launches), 0.62);
+        p.horizon_iterations = temporal_horizon(p.drift_per_launch, p.fp32, st.step);
+        if (o.temporal >= 2) p.temporal_forced = true;
+        else if (p.drift_estimate > temporal_bar(p.fp32)) {
+            char b[512];
+            snprintf(b, sizeof b, "--temporal 1 not honoured: %d on-chip stages re-associate the fused sum, and for this stencil (%zu + %zu taps), grid and "
+                                  "`iterations %d` (%d launches) the estimated drift from the reference's fused arithmetic is %.2g > %.0e relative "
+                                  "(tolerance horizon: iterations <= %d); the fused single-pass kernel is emitted instead (exact reference arithmetic; "
+                                  "--temporal force emits the pipeline anyway)",
+                     st.step, st.base.size(), st.pts.size(), st.iterations, launches, p.drift_estimate, temporal_bar(p.fp32), p.horizon_iterations);
+            p.note = b;
+            temporal = false;
+            p.drift_estimate = p.drift_per_launch = 0.0;
+            p.horizon_iterations = -1;
+        }
+    }
+    p.reassociated = temporal;
+    p.stages = temporal ? st.step : 1;
+    if (!temporal) o.temporal = 0;       // the geometry defaults below are those of the kernel that is really emitted
 
     // MI355X defaults for whatever geometry the user left unset: one wavefront (64
     // lanes) along x with 16-byte accesses per lane.
@@ -132,18 +198,6 @@ inline KernelPlan make_plan(const Stencil &st, const GenOptions &o_in, const std
         return t;
     };
     for (auto &e : st.pts.v) p.gtaps.push_back(to_tap(e, false));
-    // Temporal blocking applies the ONE-STEP stencil `step` times on chip.  It equals the
-    // reference's algebraically fused stencil (drstencil.hpp:262-282) up to rounding, provided
-    // the 6-digit rounding of the fused coefficients (drstencil.hpp:192) is a no-op; otherwise
-    // the fused single-pass kernel is emitted (exact reference arithmetic).
-    bool temporal = o.temporal && st.step > 1;
-    if (temporal)
-        for (auto &e : st.pts.v)
-            if (std::fabs(coef_rounded(e.second) - e.second) > 1e-12 * std::fabs(e.second)) temporal = false;
-    if (o.temporal && st.step > 1 && !temporal)
-        p.note = "--temporal 1 ignored: rounding the fused coefficients to 6 digits is not a no-op for this stencil, so on-chip "
-                 "stages would not equal the reference's fused arithmetic; the fused single-pass kernel is emitted instead";
-    p.stages = temporal ? st.step : 1;
     if (temporal) for (auto &e : st.base.v) p.taps.push_back(to_tap(e, true));
     else p.taps = p.gtaps;
     for (auto &t : p.taps) {

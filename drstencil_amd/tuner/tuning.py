@@ -20,8 +20,14 @@ rocprofv3 instead of Nsight Compute:
   * LDS budget 160 KiB per CU (the reference caps at 32 KiB of A100 shared memory)
   * `duration` = average kernel duration in ns from HIP events over the reference's timed
     loop (10 warm-up launches first, codegen.hpp:575-584), i.e. what `ncu ... Duration` was
-    for the reference.  Every new best is CHECKED against the emitted gold kernel before it is
-    recorded (the reference's tuner passes --check and never reads the result).
+    for the reference.  Every new best -- by duration AND by GStencil/s, the ranking objective
+    across steps -- is CHECKED against the emitted gold kernel before it is recorded, and so is
+    every configuration of the reported top of the ranking (the reference's tuner passes --check
+    and never reads the result).
+  * toleranceFilter(): `--temporal 1` configurations that the generator fenced (drift estimate
+    beyond 1e-6 / 1e-12 for the spec's iterations -> it emits the fused kernel) are dropped as
+    duplicates of their fused twins; a reassociated kernel that stays has a tolerance horizon
+    >= the spec's iterations and is timed in loops no longer than that horizon.
   * `rocprof_metrics()` then takes the best configurations through the reference's own
     per-configuration flow (tuning.py:132-137 -> compile_run.sh -> getGpuMetrics.py): drstencil
     --check -o cu/<name>.hip, hipcc, the emitted program under rocprofv3 (trace, FETCH_SIZE and
@@ -279,9 +285,28 @@ def getElapsedTime(start, end):
     return (end - start).total_seconds()
 
 
+def toleranceFilter(args):
+    """False for a `--temporal 1` configuration that the generator fenced: its drift estimate for the spec's iterations is beyond the
+    bar (1e-6 fp32 / 1e-12 fp64), so it emitted the fused kernel instead -- the same kernel as the configuration without --temporal,
+    which is in the space anyway.  Reassociated kernels that stay in the space carry a tolerance horizon >= the spec's iterations."""
+    if "--temporal" not in args:
+        return True
+    info = kernel_info(args)
+    return info is None or info.get("arithmetic") == "reassociated"
+
+
 def measure(kern, torch, A, B, iterations, warmup=10):
-    """HIP-event duration of one launch in ns, reference protocol (10 warm-ups, timed loop)."""
-    n, ms = kern.run_timed(A.data_ptr(), B.data_ptr(), iterations=iterations, warmup=warmup, stream=torch.cuda.current_stream().cuda_stream)
+    """HIP-event duration of one launch in ns, reference protocol (10 warm-ups, timed loop).  A temporal pipeline is only run up to
+    its tolerance horizon (drs_kernel_run refuses more): several short timed loops instead of one long one."""
+    hz = kern.info.get("tolerance_horizon_iterations", -1)
+    stream = torch.cuda.current_stream().cuda_stream
+    if kern.info.get("arithmetic") == "reassociated" and not kern.info.get("temporal_forced") and 0 < hz < iterations:
+        n = ms = 0
+        for rep in range(-(-iterations // hz)):
+            n1, ms1 = kern.run_timed(A.data_ptr(), B.data_ptr(), iterations=hz, warmup=warmup if rep == 0 else 0, stream=stream)
+            n, ms = n + n1, ms + ms1
+        return ms * 1e6 / max(n, 1)
+    n, ms = kern.run_timed(A.data_ptr(), B.data_ptr(), iterations=iterations, warmup=warmup, stream=stream)
     return ms * 1e6 / max(n, 1)
 
 
@@ -381,8 +406,11 @@ def searchSpace(stc, is3d, dtype, configs, outdir, iterations=8, budget_s=None, 
     base = (["--3d"] if is3d else []) + ["--dtype", dtype] + list(extra_opts)
     jobsl = [(n, base + a + [stc]) for n, a in named]
     nall = len(jobsl)
+    jobsl = [j for j in jobsl if toleranceFilter(j[1])]
+    nfenced = nall - len(jobsl)
     jobsl = [j for j in jobsl if registerFilter(j[1])]
-    print("{0} configurations, {1} dropped by the register model before compiling".format(nall, nall - len(jobsl)), flush=True)
+    print("{0} configurations, {1} temporal ones fenced by the generator's drift estimate (they would be the fused kernel), {2} dropped by the register model before compiling"
+          .format(nall, nfenced, nall - nfenced - len(jobsl)), flush=True)
     argmap = dict(jobsl)
     t_start = time.time()
     pool = ProcessPoolExecutor(max_workers=jobs, mp_context=multiprocessing.get_context("forkserver"))
@@ -393,6 +421,7 @@ def searchSpace(stc, is3d, dtype, configs, outdir, iterations=8, budget_s=None, 
     torch = None
     A = B = G = None
     best = 1e18
+    best_gst = 0.0
     results = []
     esz = 4 if dtype == "fp32" else 8
     nfail = nwrong = 0
@@ -417,9 +446,11 @@ def searchSpace(stc, is3d, dtype, configs, outdir, iterations=8, budget_s=None, 
         gst = kern.updates_per_launch() / dur
         rec = dict(name=name, args=" ".join(argmap[name][:-1]), duration_ns=dur, GBps=gbs, frac=gbs / 8000.0, GStencil=gst,
                    lds=kern.info["lds_bytes"], threads=kern.info["threads"], step=kern.info["step"], schedule=kern.info.get("schedule"),
-                   vgprs=kern.resources.get("vgprs"), agprs=kern.resources.get("agprs"), reg_demand=kern.info.get("reg_demand"))
-        if dur < best:
-            # a configuration is recorded as the best only if it computes what the gold kernel computes
+                   vgprs=kern.resources.get("vgprs"), agprs=kern.resources.get("agprs"), reg_demand=kern.info.get("reg_demand"),
+                   arithmetic=kern.info.get("arithmetic"), tolerance_horizon_iterations=kern.info.get("tolerance_horizon_iterations"), verified=None)
+        if dur < best or gst > best_gst:
+            # a configuration is recorded as a best -- by duration (duration.log, the reference's objective for one step) or by
+            # GStencil/s (the ranking across steps) -- only if it computes what the gold kernel computes
             good, rel = verify(kern, torch, A, B, G)
             rec["verified"], rec["max_rel_vs_gold"] = bool(good), rel
             A.uniform_()                                # the check overwrote B; fresh input for the next measurement
@@ -436,6 +467,7 @@ def searchSpace(stc, is3d, dtype, configs, outdir, iterations=8, budget_s=None, 
             continue
         print("{0}/{1}: {2}  {3:.0f} ns  {4:.0f} GB/s ({5:.1f}%)  {6:.1f} GStencil/s".format(
             cnt, len(jobsl), name, dur, gbs, gbs / 80.0, gst), flush=True)
+        best_gst = max(best_gst, gst)
         if dur < best:
             best = dur
             with open(os.path.join(outdir, "duration.log"), "a") as f:
@@ -450,6 +482,28 @@ def searchSpace(stc, is3d, dtype, configs, outdir, iterations=8, budget_s=None, 
     # the reference minimises Duration for a fixed step; across steps the objective is updates per second
     results = [r for r in results if "duration_ns" in r]
     results.sort(key=lambda r: -r["GStencil"])
+    # the reported winners (best: list, --profile-top) are the top of THIS ranking: every one of them is compared with the gold
+    # kernel before it is reported (a configuration that never set a running best has not been checked yet); wrong ones are dropped
+    top_n = max(10, profile_top)
+    checked = []
+    for r in results:
+        if len(checked) >= top_n:
+            break
+        if r.get("verified") is None and torch is not None:
+            kern = drs.Kernel(argmap[r["name"]])
+            good, rel = verify(kern, torch, A, B, G)
+            A.uniform_()
+            r["verified"], r["max_rel_vs_gold"] = bool(good), rel
+            if not keep_loaded:
+                kern.unload()
+            with open(os.path.join(outdir, "results.jsonl"), "a") as f:
+                f.write(json.dumps(dict(r, recheck="top of the ranking")) + "\n")
+            if not good:
+                nwrong += 1
+                print("{0} WRONG RESULT (max rel {1:.3g} vs gold): dropped from the ranking".format(r["name"], rel), flush=True)
+                continue
+        checked.append(r)
+    results = checked + [r for r in results if r not in checked and r.get("verified") is not False]
     print("{0} timed, {1} build failures, {2} wrong results dropped".format(len(results), nfail, nwrong), flush=True)
     if profile_top and results:
         del A, B, G
@@ -496,7 +550,7 @@ def main():
                       extra_opts=a.extra.split())
     print("best:")
     for r in res[:10]:
-        print("  {name}  {duration_ns:.0f} ns  {GBps:.0f} GB/s  {GStencil:.1f} GStencil/s".format(**r))
+        print("  {name}  {duration_ns:.0f} ns  {GBps:.0f} GB/s  {GStencil:.1f} GStencil/s  verified vs gold: {verified}  arithmetic: {arithmetic}".format(**r))
 
 
 if __name__ == "__main__":

@@ -55,7 +55,14 @@ void drs_kernel_close(drs_kernel *k);                /* frees the handle; the pl
  * For long sweeps that load thousands of kernels (the tuner: benchmarks/3d7pt_star/tuning.py:102-142 starts one process
  * per configuration instead).  Not to be called while one of its launches may still be running on another device. */
 int drs_kernel_unload(drs_kernel *k);
-const char *drs_kernel_info(const drs_kernel *k);   /* JSON: dims, dtype, halo, step, grid, lds ... */
+/* JSON: dims, dtype, halo, step, grid, lds ... and which arithmetic the kernel computes:
+ *   "arithmetic": "gold-order"    the reference's fused sum (drstencil.hpp:182-196, 262-282) as one FMA chain -- bit-identical
+ *                                  to gold_<name> for any iteration count ("tolerance_horizon_iterations": -1);
+ *                 "reassociated"  on-chip time steps (--temporal 1 / force): equal to it up to rounding; the generator emits
+ *                                  such a kernel only where its drift estimate ("drift_estimate", relative, for the spec's
+ *                                  iterations) stays within 1e-6 (fp32) / 1e-12 (fp64), "tolerance_horizon_iterations" is the
+ *                                  largest iteration count for which it does, and "temporal_forced": 1 marks --temporal force. */
+const char *drs_kernel_info(const drs_kernel *k);
 const char *drs_kernel_path(const drs_kernel *k);   /* the loaded shared object */
 /* JSON: vgprs, agprs, sgprs, scratch_bytes_per_lane, sgpr_spill, vgpr_spill, occupancy_waves_per_simd, lds_bytes of
  * dr_<name> (with --pair-launch: the maximum over dr_<name> and dr2_<name>) as reported by hipcc -- what the reference reads
@@ -75,7 +82,8 @@ int drs_kernel_launch_pair(drs_kernel *k, const void *d_in0, void *d_out0, const
 int drs_kernel_launch_gold(drs_kernel *k, const void *d_in, void *d_out, void *stream);
 /* the timed ping-pong loop: for (t = 0; t < iterations; t += 2*step) { k(A,B); k(B,A); }
  * (codegen.hpp:581-584).  gold != 0 runs gold_<name> instead.  Returns the number of
- * launches, or -1 on a HIP error.  Asynchronous on `stream`. */
+ * launches, -1 on a HIP error, or -3 when `iterations` exceeds the tolerance horizon of a reassociated (temporal) kernel
+ * that was not built with --temporal force: build the fused kernel for such a run.  Asynchronous on `stream`. */
 int drs_kernel_run(drs_kernel *k, void *d_a, void *d_b, int iterations, int gold, void *stream);
 /* `warmup` untimed launches (A,B) (codegen.hpp:575-578), then the loop above bracketed by
  * HIP events recorded on `stream`; blocks until done; *ms = elapsed milliseconds. */

@@ -41,6 +41,11 @@ def lib():
         for n in ("drso_halo", "drso_iterations", "drso_npts"):
             getattr(L, n).argtypes = [ctypes.c_void_p]
         L.drso_srand.argtypes = [ctypes.c_uint]
+        for n in ("drso_first_touch_f64", "drso_first_touch_f32"):
+            getattr(L, n).argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+        for n in ("drso_copy_f64", "drso_copy_f32"):
+            getattr(L, n).argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+        L.drso_isa.restype = ctypes.c_char_p
         _LIB = L
     return _LIB
 
@@ -135,3 +140,22 @@ def check(spec, out, ref):
 
 def threads():
     return lib().drso_threads()
+
+
+def isa():
+    """The clone of the sweep the loader picked on this host: avx512f | avx2+fma | baseline."""
+    return lib().drso_isa().decode()
+
+
+def empty_first_touched(spec, dtype):
+    """A zeroed array of the spec's shape whose pages were first written by the OpenMP threads that will sweep them (same static
+    (k, j) schedule as the sweep): on a two-socket host every thread's rows then live on its own NUMA node."""
+    a = np.empty(spec.shape, dtype=dtype)       # untouched pages (large allocations come straight from mmap)
+    getattr(lib(), "drso_first_touch_" + _sfx(a))(spec.p, a.ctypes.data)
+    return a
+
+
+def copy_into(spec, dst, src):
+    """dst[:] = src with the sweep's thread schedule."""
+    assert dst.dtype == src.dtype and dst.shape == src.shape and src.flags.c_contiguous
+    getattr(lib(), "drso_copy_" + _sfx(dst))(spec.p, dst.ctypes.data, src.ctypes.data)

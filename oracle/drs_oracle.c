@@ -193,7 +193,24 @@ void drso_fill_random_f32(float *a, size_t n)
  *   contract == 1: t = c0*a0; t = fma(ci, ai, t) -- what a device compiler with
  *                  FMA contraction makes of the same left-to-right expression,
  *                  and what the HIP kernels compute. */
+/* Implementation notes (round 3: the sweep is also bench.py's cpu_baseline, so it should not be a strawman):
+ *   * rows are processed in blocks of DRSO_BLK points; inside a block the TAP loop is the outer one and the point loop the
+ *     inner one, so the compiler vectorises ACROSS points (AVX-512 / AVX2 FMA) while every point still runs its own chain
+ *     t = c0*a0; t = fma(ci, ai, t) in table order -- the rounding sequence of each output is exactly the scalar one, and
+ *     the golden-fixture tests stay bit-exact;
+ *   * target_clones: the .so is built in one container and runs on the GPU box's host (2 x EPYC 9575F), so the ISA is picked
+ *     at load time (avx512f / avx2+fma / baseline), never by -march=native;
+ *   * OpenMP over (k, j) rows, static schedule -- drso_first_touch_* uses the same schedule so that on a two-socket box
+ *     every thread's rows live on its own NUMA node. */
+#define DRSO_BLK 128
+#if defined(__x86_64__) && defined(__GNUC__) && !defined(__clang__)
+#define DRSO_CLONES __attribute__((target_clones("avx512f", "arch=haswell", "default")))
+#else
+#define DRSO_CLONES
+#endif
+
 #define DEF_SWEEP(NAME, T, FMA)                                                          \
+DRSO_CLONES                                                                              \
 void NAME(const drso_spec *s, const T *src, T *dst, int contract)                       \
 {                                                                                        \
     const int H = s->halo, L = s->L, M = s->M, N = s->N, np = s->npts;                   \
@@ -208,27 +225,60 @@ void NAME(const drso_spec *s, const T *src, T *dst, int contract)               
     for (int k = klo; k < khi; k++)                                                      \
         for (int j = H; j < M - H; j++) {                                                \
             const size_t row = ((size_t)k * M + j) * N;                                  \
-            if (contract) {                                                              \
-                for (int i = H; i < N - H; i++) {                                        \
-                    const T *c = src + row + i;                                          \
-                    T t = cf[0] * c[doff[0]];                                            \
-                    for (int p = 1; p < np; p++) t = FMA(cf[p], c[doff[p]], t);          \
-                    dst[row + i] = t;                                                    \
+            for (int i0 = H; i0 < N - H; i0 += DRSO_BLK) {                               \
+                const int n = (N - H - i0 < DRSO_BLK) ? N - H - i0 : DRSO_BLK;           \
+                const T *c = src + row + i0;                                             \
+                T t[DRSO_BLK];                                                           \
+                {                                                                        \
+                    const T *a = c + doff[0]; const T w = cf[0];                         \
+                    for (int x = 0; x < n; x++) t[x] = w * a[x];                         \
                 }                                                                        \
-            } else {                                                                     \
-                for (int i = H; i < N - H; i++) {                                        \
-                    const T *c = src + row + i;                                          \
-                    T t = cf[0] * c[doff[0]];                                            \
-                    for (int p = 1; p < np; p++) t = t + cf[p] * c[doff[p]];             \
-                    dst[row + i] = t;                                                    \
+                if (contract) {                                                          \
+                    for (int p = 1; p < np; p++) {                                       \
+                        const T *a = c + doff[p]; const T w = cf[p];                     \
+                        for (int x = 0; x < n; x++) t[x] = FMA(w, a[x], t[x]);           \
+                    }                                                                    \
+                } else {                                                                 \
+                    for (int p = 1; p < np; p++) {                                       \
+                        const T *a = c + doff[p]; const T w = cf[p];                     \
+                        for (int x = 0; x < n; x++) t[x] = t[x] + w * a[x];              \
+                    }                                                                    \
                 }                                                                        \
+                memcpy(dst + row + i0, t, sizeof(T) * (size_t)n);                        \
             }                                                                            \
         }                                                                                \
     free(doff); free(cf);                                                                \
 }
 
-DEF_SWEEP(drso_sweep_f64, double, fma)
-DEF_SWEEP(drso_sweep_f32, float, fmaf)
+DEF_SWEEP(drso_sweep_f64, double, __builtin_fma)
+DEF_SWEEP(drso_sweep_f32, float, __builtin_fmaf)
+
+/* The pages of a freshly allocated (untouched) array are placed on the NUMA node of the thread that writes them first:
+ * zero-fill with the sweep's own (k, j) schedule, whole rows including the ring. */
+#define DEF_TOUCH(NAME, T)                                                               \
+void NAME(const drso_spec *s, T *a)                                                      \
+{                                                                                        \
+    const int L = (s->ndim == 3) ? s->L : 1, M = s->M, N = s->N;                         \
+    _Pragma("omp parallel for collapse(2) schedule(static)")                             \
+    for (int k = 0; k < L; k++)                                                          \
+        for (int j = 0; j < M; j++)                                                      \
+            memset(a + ((size_t)k * M + j) * N, 0, sizeof(T) * (size_t)N);               \
+}
+DEF_TOUCH(drso_first_touch_f64, double)
+DEF_TOUCH(drso_first_touch_f32, float)
+
+/* parallel copy with the same schedule (fills a first-touched array from a host buffer) */
+#define DEF_COPY(NAME, T)                                                                \
+void NAME(const drso_spec *s, T *dst, const T *src)                                      \
+{                                                                                        \
+    const int L = (s->ndim == 3) ? s->L : 1, M = s->M, N = s->N;                         \
+    _Pragma("omp parallel for collapse(2) schedule(static)")                             \
+    for (int k = 0; k < L; k++)                                                          \
+        for (int j = 0; j < M; j++)                                                      \
+            memcpy(dst + ((size_t)k * M + j) * N, src + ((size_t)k * M + j) * N, sizeof(T) * (size_t)N); \
+}
+DEF_COPY(drso_copy_f64, double)
+DEF_COPY(drso_copy_f32, float)
 
 /* ---- the whole run: codegen.hpp:581-584 / codegen_2d.hpp host loop.
  * for (t = 0; t < Iterations; t += 2*step) { launch(A,B); launch(B,A); }
@@ -300,6 +350,16 @@ void drso_dims(const drso_spec *s, int *L, int *M, int *N) { *L = s->L; *M = s->
 void drso_point(const drso_spec *s, int p, int *k, int *j, int *i, double *c)
 {
     *k = s->off[p][0]; *j = s->off[p][1]; *i = s->off[p][2]; *c = s->coef[p];
+}
+/* which clone of the sweep the loader picked on this host (reported by bench.py's cpu_baseline) */
+const char *drso_isa(void)
+{
+#if defined(__x86_64__) && defined(__GNUC__) && !defined(__clang__)
+    __builtin_cpu_init();
+    if (__builtin_cpu_supports("avx512f")) return "avx512f";
+    if (__builtin_cpu_supports("avx2") && __builtin_cpu_supports("fma")) return "avx2+fma";
+#endif
+    return "baseline";
 }
 int drso_threads(void)
 {

@@ -26,7 +26,12 @@ declare -A PMC=(
   [grbm]="GRBM_GUI_ACTIVE GRBM_COUNT"
 )
 timeout -k 10 250 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -- "${B[@]}" > $out/trace.log 2>&1 || exit 2
+# a failed pass leaves a partial (or a previous run's) counter directory behind: it is removed and named to summarize_pmc.py, which
+# then writes no traffic figure when fetch or write is missing, and the script exits non-zero after summarising what it has
+failed=""
 for pass in ${PASSES:-fetch write tcc sq}; do
-  timeout -k 10 200 rocprofv3 --kernel-trace --pmc ${PMC[$pass]} --output-format csv -d $out/$pass -- "${B[@]}" > $out/$pass.log 2>&1 || { echo "pass $pass failed"; tail -3 $out/$pass.log; }
+  rm -rf $out/$pass
+  timeout -k 10 200 rocprofv3 --kernel-trace --pmc ${PMC[$pass]} --output-format csv -d $out/$pass -- "${B[@]}" > $out/$pass.log 2>&1 || { echo "pass $pass failed"; tail -3 $out/$pass.log; rm -rf $out/$pass; failed="$failed $pass"; }
 done
-python3 scripts/summarize_pmc.py $tag "${B[*]}" $STEPS
+FAILED_PASSES="$failed" python3 scripts/summarize_pmc.py $tag "${B[*]}" $STEPS || exit 7
+[ -z "$failed" ] || { echo "profile_bench.sh: failed passes:$failed"; exit 6; }

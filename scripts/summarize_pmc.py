@@ -85,7 +85,10 @@ for f in sorted(glob.glob(os.path.join(root, "*/*/*counter_collection.csv"))):
         if timed and len(vals) >= timed:
             vals = vals[-timed:]
         out[k] = sum(vals) / len(vals)
-if "FETCH_SIZE" in out and "WRITE_SIZE" in out:
+failed = os.environ.get("FAILED_PASSES", "").split()
+if failed:
+    out["failed_passes"] = failed          # profile_bench.sh removed their directories: nothing of them (or of an older run) is summarised
+if "FETCH_SIZE" in out and "WRITE_SIZE" in out and not ({"fetch", "write"} & set(failed)):
     out["fetch_bytes_corrected_x2"] = out["FETCH_SIZE"] * 1024 * 2
     out["write_bytes"] = out["WRITE_SIZE"] * 1024
     out["traffic_bytes_per_launch"] = out["fetch_bytes_corrected_x2"] + out["write_bytes"]

@@ -74,9 +74,12 @@ def check(job, k, torch):
         ring = np.ones(A.shape, bool); ring[tuple(slice(h, s - h) for s in A.shape)] = False
         bar = 1e-6 if dtype == "fp32" else 1e-12
         ring_ok = np.array_equal(A[ring], Ar[ring]) and np.array_equal(B[ring], Br[ring])
-        # "drift": an on-chip pipeline rounds its intermediate planes, the fused stencil does not -- beyond the bar but within 10x
-        # of it (and the ring untouched) is rounding, not logic; it is counted and reported separately, never as a pass
-        return ("ok" if rel <= bar and ring_ok else "drift" if rel <= 10 * bar and ring_ok else "bad"), True, rel
+        # A temporal pipeline that the generator emitted on its own (--temporal 1) CLAIMS the bar: beyond it is a failure like any
+        # other mismatch (the generator's drift estimate, planner.hpp: temporal_drift_per_launch, was wrong).  "drift" exists only for
+        # --temporal force kernels: beyond the bar but within 10x of it (and the ring untouched) is the rounding of the
+        # intermediate planes the caller asked to see, counted and reported separately, never as a pass
+        forced = bool(k.info.get("temporal_forced"))
+        return ("ok" if rel <= bar and ring_ok else "drift" if forced and rel <= 10 * bar and ring_ok else "bad"), True, rel
     return ("ok" if np.array_equal(A, Ar) and np.array_equal(B, Br) else "bad"), False, 0.0
 
 

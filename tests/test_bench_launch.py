@@ -17,6 +17,8 @@ keys = ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "MASTER_ADDR", "
 json.dump({"argv": sys.argv[1:], "env": {k: os.environ.get(k) for k in keys}, "pid": os.getpid()}, open(os.path.join(out, tag + ".json"), "w"))
 if tag == "prebuild":
     sys.exit(0)
+if os.environ.get("STUB_HANG"):
+    time.sleep(120)         # a rank stuck in a rendezvous: only the launcher's deadline ends it
 fail = os.environ.get("STUB_FAIL_RANK")
 if fail is not None:
     if os.environ["RANK"] == fail:
@@ -73,6 +75,15 @@ def test_a_failed_rank_ends_the_others_and_the_exit_code_is_propagated(tmp_path)
     r = _run(tmp_path, ["--gpus", "3"], {"STUB_FAIL_RANK": "1"})
     assert r.returncode == 3, (r.returncode, r.stdout, r.stderr)
     assert time.time() - t0 < 30, "the surviving ranks were not terminated"
+
+
+def test_hung_ranks_are_ended_at_the_deadline(tmp_path):
+    """spawn_ranks used to poll for ever when a rank hangs without exiting; --rank-timeout ends the ranks and the
+    launcher exits 124."""
+    t0 = time.time()
+    r = _run(tmp_path, ["--gpus", "2", "--rank-timeout", "2"], {"STUB_HANG": "1"})
+    assert r.returncode == 124, (r.returncode, r.stdout, r.stderr)
+    assert time.time() - t0 < 30 and "still running after 2 s" in r.stderr
 
 
 def test_world_size_mismatch_is_refused_before_the_gpu_is_touched(tmp_path):

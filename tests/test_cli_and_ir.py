@@ -146,3 +146,65 @@ def test_temporal_fallback_is_reported(tmp_path):
     assert '\\"stages\\":1' in src
     rc, msg, src = drs.generate(["--3d", "--dtype", "fp32", "--step", "2", "--temporal", "1", os.path.join(ROOT, "tests", "stc", "t3_star.stc")])
     assert rc == 0 and "note:" not in msg and '\\"stages\\":2' in src
+
+
+def test_temporal_blocking_is_fenced_to_the_tolerance(tmp_path):
+    """On-chip time steps re-associate the reference's fused sum (drstencil.hpp:262-282).  `--temporal 1` emits them only where
+    the generator's drift estimate (planner.hpp: temporal_drift_per_launch, calibrated: profiles/r03_temporal_drift_calibration.txt)
+    keeps 1e-6 relative (fp32) / 1e-12 (fp64) for the spec's iterations, and the fused kernel -- exact reference arithmetic --
+    otherwise, with a note; `--temporal force` emits them regardless and the plugin says so."""
+    import json
+    import re
+    import drstencil_amd as drs
+
+    def info(src):
+        m = re.search(r'return "(\{.*\})";', src)
+        return json.loads(m.group(1).replace('\\"', '"'))
+
+    it4 = os.path.join(ROOT, "tests", "stc", "t3_star.stc")            # iterations 4
+    it100 = os.path.join(ROOT, "tests", "stc", "t3_star_it100.stc")    # iterations 100
+    base = ["--3d", "--dtype", "fp32", "--step", "2"]
+    rc, msg, src = drs.generate(base + ["--temporal", "1", it4])
+    i = info(src)
+    assert rc == 0 and i["stages"] == 2 and i["arithmetic"] == "reassociated" and i["temporal_forced"] == 0
+    assert 0 < i["drift_estimate"] <= 1e-6 and i["iterations"] <= i["tolerance_horizon_iterations"] < 100
+    assert "// arithmetic: reassociated" in src
+    # 100 iterations: beyond the horizon -> the fused kernel, and the user is told
+    rc, msg, src = drs.generate(base + ["--temporal", "1", it100])
+    i = info(src)
+    assert rc == 0 and i["stages"] == 1 and i["arithmetic"] == "gold-order" and i["tolerance_horizon_iterations"] == -1 and i["drift_estimate"] == 0
+    assert "note: --temporal 1 not honoured" in msg and "// note: --temporal 1 not honoured" in src and "// arithmetic: gold order" in src
+    # ... unless forced
+    rc, msg, src = drs.generate(base + ["--temporal", "force", it100])
+    i = info(src)
+    assert rc == 0 and i["stages"] == 2 and i["arithmetic"] == "reassociated" and i["temporal_forced"] == 1 and i["drift_estimate"] > 1e-6
+    assert "emitted by --temporal force" in src and "note:" not in msg
+    # three stages on the full C4 grid are beyond the bar even at iterations 4 (measured 9.65e-7 at 1024^3: no margin); two stages are within
+    c4 = os.path.join(ROOT, "benchmarks", "configs", "c4_3d7pt_star_1024.stc")
+    assert info(drs.generate(["--3d", "--dtype", "fp32", "--step", "3", "--temporal", "1", c4])[2])["stages"] == 1
+    assert info(drs.generate(["--3d", "--dtype", "fp32", "--step", "2", "--temporal", "1", c4])[2])["stages"] == 2
+    # fp64 has 29 bits more: the same pipelines are far inside 1e-12
+    i = info(drs.generate(["--3d", "--dtype", "fp64", "--step", "3", "--temporal", "1", it100])[2])
+    assert i["stages"] == 3 and i["drift_estimate"] < 1e-13 and i["tolerance_horizon_iterations"] > 1000
+    # the estimate grows with the stages, the taps and the launches
+    e = lambda step, stc: info(drs.generate(["--3d", "--dtype", "fp32", "--step", str(step), "--temporal", "force", stc])[2])["drift_estimate"]
+    assert e(2, it4) < e(3, it4) and e(2, it4) < e(2, it100)
+    # a fused kernel is gold order whatever the step
+    assert info(drs.generate(base + [it100])[2])["arithmetic"] == "gold-order"
+    # the option takes 0 | 1 | force
+    rc, msg, src = drs.generate(base + ["--temporal", "maybe", it4])
+    assert rc == 255 and "Illegal input." in msg and not src
+
+
+def test_temporal_kernel_refuses_iterations_beyond_its_horizon():
+    """drs_kernel_run answers -3 before anything is launched when a reassociated kernel (not forced) is asked for more iterations than
+    its tolerance horizon (include/drstencil_amd.h); no GPU needed to see that."""
+    import drstencil_amd as drs
+    from gpu_cases import SMALL
+    cid, ndim, stc, opts = next(c for c in SMALL if c[0] == "3d7_fp32_t2")
+    kern = drs.Kernel(opts + [stc])                                   # built by build(); cross-compiles if not
+    assert kern.info["arithmetic"] == "reassociated"
+    with pytest.raises(drs.ToleranceHorizonExceeded):
+        kern.run(0, 0, iterations=kern.info["tolerance_horizon_iterations"] + 1)
+    with pytest.raises(drs.ToleranceHorizonExceeded):
+        kern.run_timed(0, 0, iterations=100)
