@@ -83,6 +83,15 @@ MI355X options:
                         plane's in-plane neighbours are kept in registers when that plane has at least --merge-forward
                         in-plane taps, else re-read from LDS when they are due;
                         window: every contributing plane resident, nothing carried.
+--order <taps|rows>     Emission order of a plane's FMAs (scatter schedule; results never depend on it).  taps (default): one
+                        chain per partial sum, the plane's whole rim window read up front.  rows: the arriving plane is
+                        consumed one source row at a time, each row's tap groups fenced from the next (sched_barrier), so
+                        that the compiler cannot stretch every row's reads over the whole plane (register pressure).
+--pack <0|1>            With --order rows, fp32: two adjacent x points per v_pk_fma_f32 (bit-identical results; default 1).
+--pin <0|1>             Pass every partial sum through an empty asm statement where it is updated, so that the compiler cannot
+                        sink the FMA chains of the unrolled streaming loop down to the store (which keeps `Range` planes of
+                        source windows alive instead of the sums; default: 1 with --order rows, else 0).
+--row-fence <mask>      sched_barrier mask between row groups (0 default: nothing crosses; -1: no fence).
 --temporal <0|1|force>  With --step n > 1: run the one-step stencil n times on chip (temporal blocking,
                         intermediate planes never leave the CU) instead of the fused stencil.  On-chip stages
                         re-associate the fused sum: 1 emits them only where the estimated drift from the reference's
@@ -166,6 +175,10 @@ inline GenResult generate(const std::vector<std::string> &args /* argv[1..] */) 
         else if (a == "--dtype") { if (!str_opt(o.dtype)) break; }
         else if (a == "--xrim") { if (!str_opt(o.xrim)) break; }
         else if (a == "--schedule") { if (!str_opt(o.schedule)) break; o.schedule_set = true; }
+        else if (a == "--order") { if (!str_opt(o.order)) break; }
+        else if (a == "--pack") { if (!int_opt(o.pack, nullptr)) break; }
+        else if (a == "--row-fence") { if (!int_opt(o.row_fence, nullptr)) break; }
+        else if (a == "--pin") { if (!int_opt(o.pin, nullptr)) break; }
         else if (a == "--exact-y") { if (!int_opt(o.exact_y, nullptr)) break; }
         else if (a == "--exact-x") { if (!int_opt(o.exact_x, nullptr)) break; }
         else if (a == "--xedge-select") { if (!int_opt(o.xedge_select, nullptr)) break; }
@@ -204,6 +217,7 @@ inline GenResult generate(const std::vector<std::string> &args /* argv[1..] */) 
     // an explicit --dist selects the reference's kind of reuse: `Range` source planes resident, the rest carried as partial sums
     if (!o.schedule_set && o.dist != 0) o.schedule = "reuse";
     if (o.schedule != "scatter" && o.schedule != "window" && o.schedule != "reuse") { res.messages += "Illegal input.\n"; res.exit_code = 255; return res; }
+    if (o.order != "taps" && o.order != "rows") { res.messages += "Illegal input.\n"; res.exit_code = 255; return res; }
     if (o.xrim != "lds" && o.xrim != "dpp") { res.messages += "Illegal input.\n"; res.exit_code = 255; return res; }
     if (o.stage != "reg" && o.stage != "dma") { res.messages += "Illegal input.\n"; res.exit_code = 255; return res; }
     if (o.store_mask != "buffer" && o.store_mask != "branch") { res.messages += "Illegal input.\n"; res.exit_code = 255; return res; }
@@ -224,6 +238,7 @@ inline GenResult generate(const std::vector<std::string> &args /* argv[1..] */) 
     std::string cmdline;
     for (size_t i = 0; i + 1 < args.size(); i++) cmdline += (i ? " " : "") + args[i];
     HipEmitter em(res.plan, o);
+    if (!em.config_error().empty()) { res.messages += "Invalid configuration!\n"; res.exit_code = 255; res.plan.error = em.config_error(); return res; }
     if (em.lds_bytes() > 160 * 1024) {   // gfx950: 160 KiB of LDS per workgroup
         res.messages += "Invalid configuration!\n"; res.exit_code = 255; res.plan.error = "tile needs more than 160 KiB of LDS"; return res;
     }

@@ -120,6 +120,23 @@ struct GenOptions {
     std::string schedule = "scatter";  // scatter: every partial sum carried in VGPRs; window: rotating register windows, nothing carried;
                                  // reuse: `Range` planes in register windows + the rest carried (the reference's split for --dist)
     bool schedule_set = false;   // --schedule given (else an explicit --dist selects "reuse")
+    // Round 3: the emitter bounds the live ranges itself instead of leaving a straight-line plane body to the compiler's pre-RA scheduler
+    // (named state 136 words -> 256 VGPRs + scratch for the fused 63-point stencil).
+    std::string order = "taps";  // scatter schedule, emission order of a plane's FMAs.  taps: every partial sum's chain in one piece, the whole rim
+                                 // window read up front (rounds 1-2).  rows: by SOURCE ROW -- the arriving plane is consumed one row at a time
+                                 // (the row's own-column vector from registers / one LDS read, its x neighbours by DPP), each row's tap groups
+                                 // fenced from the next with __builtin_amdgcn_sched_barrier, the next row's LDS read issued one group ahead.
+                                 // Gold order is kept: for a fixed output the taps still arrive sorted by (streamed offset, row, column)
+    int pack = -1;               // --order rows, fp32: sums of two adjacent x points as float2 halves of the accumulator vectors and
+                                 // __builtin_elementwise_fma on float2 operands -> v_pk_fma_f32 (two FMAs per lane and issue slot; each half is an
+                                 // IEEE fma, so results stay bit-identical).  Pairs that start at an odd column are assembled from DPP moves.  -1 auto
+    int pin = -1;                // 1: every partial sum a plane iteration (taps) / a row group (rows) has updated is passed through an empty
+                                 // `asm volatile("" : "+v"(sum))` at its end.  Without it LLVM SINKS the FMA chains of the unrolled loop down to
+                                 // the block that stores the finished plane -- the chain of an output spans `Range` unrolled iterations and has no
+                                 // other use -- and keeps the SOURCE windows of all those planes alive instead of one partial sum (seen in the
+                                 // ISA: one mul + 62 FMAs on one register pair right in front of the store, 370 live values for 136 named
+                                 // ones, profiles/r03_sinking.md).  The pin makes each update used where it is written.  -1 auto: on with --order rows
+    int row_fence = 0;           // mask of __builtin_amdgcn_sched_barrier between row groups (0: nothing crosses; -1: no fence)
 };
 
 struct Tap {

@@ -277,6 +277,11 @@ def registerFilter(args):
     info = kernel_info(args)
     if info is None:
         return True            # let the build report the generator's own error
+    if info.get("pinned"):
+        # round 3: with --pin / --order rows the compiler can no longer sink the FMA chains and stretch the source windows over
+        # `Range` iterations, so what it allocates is the generator's named state plus addressing (measured: 98-136 VGPRs for
+        # reg_demand 100-136, profiles/r03_exp_r3a.log); the logistic model above was fitted to unpinned kernels
+        return info["reg_demand"] + 24 <= min(256, lane_register_budget(info["threads"]))
     return spill_probability(info, prefetch_depth_of(args)) <= SPILL_THRESHOLD
 
 

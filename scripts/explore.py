@@ -53,6 +53,11 @@ def main():
     with ProcessPoolExecutor(max_workers=min(16, os.cpu_count())) as ex:
         res = list(ex.map(_build, [j[4] for j in jobs]))
     print("built in %.0f s" % (time.time() - t0), flush=True)
+    if os.environ.get("EXPLORE_BUILD_ONLY"):      # fill the kernel cache on a box without a GPU (the cache travels with the tree)
+        for j, (ok, info) in zip(jobs, res):
+            if not ok:
+                print(j[0], "BUILD FAILED", info.splitlines()[-1] if info else "", flush=True)
+        return
     kerns = []
     for j, (ok, info) in zip(jobs, res):
         if not ok:
@@ -79,6 +84,27 @@ def main():
         print("copy %d MiB: %.3f ms  %.0f GB/s (read+write)" % (nbytes >> 20, ms, 2 * nbytes / ms / 1e6), flush=True)
         out.write(json.dumps(dict(name="copy_%dMiB" % (nbytes >> 20), ms=ms, GBps=2 * nbytes / ms / 1e6)) + "\n")
         del a, b
+    if os.environ.get("EXPLORE_VERIFY"):
+        # one launch of every kernel against its own gold kernel (bit for bit; temporal pipelines: max relative difference printed)
+        for (name, ndim, d, dtype, args), k in kerns:
+            if name.startswith("gold") or not k.info.get("valid", 1):
+                continue
+            tdt = torch.float32 if dtype == "fp32" else torch.float64
+            shape = tuple(d) if ndim == 3 else tuple(d[1:])
+            g = torch.Generator(device="cuda").manual_seed(5)
+            A = torch.rand(shape, dtype=tdt, device="cuda", generator=g)
+            B = torch.zeros_like(A); G = torch.zeros_like(A)
+            k.launch(A.data_ptr(), B.data_ptr()); k.launch_gold(A.data_ptr(), G.data_ptr())
+            torch.cuda.synchronize()
+            if torch.equal(B, G):
+                print("verify %-28s == gold kernel, bit for bit (%s, %s VGPRs, %s scratch)" % (name, k.info.get("arithmetic"), k.resources.get("vgprs"), k.resources.get("scratch_bytes_per_lane")), flush=True)
+            else:
+                h = k.info["halo"]
+                inner = tuple(slice(h, n - h) for n in shape)
+                rel = float(((B[inner] - G[inner]).abs() / G[inner].abs().clamp_min(1e-30)).max())
+                print("verify %-28s DIFFERS from the gold kernel: max rel %.3g (%s)" % (name, rel, k.info.get("arithmetic")), flush=True)
+            del A, B, G
+        torch.cuda.empty_cache()
     rounds = int(os.environ.get("EXPLORE_ROUNDS", "1"))
     agg = {}
     order_names = []

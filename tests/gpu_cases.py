@@ -82,6 +82,25 @@ _add("2d25_fp64_stream_overlap_x", 2, "t2_box25", "--dtype", "fp64", "--streamin
 _add("3d7_fp32_s2_defer_stores", 3, "t3_star", "--dtype", "fp32", "--step", "2", "--sn", "16", "--bx", "32", "--by", "8", "--block-merge-y", "2", "--prefetch", "--prefetch-depth", "1", "--defer-stores", "1")
 _add("3dodd_fp64_defer_stores_dma", 3, "t3_odd", "--dtype", "fp64", "--stage", "dma", "--defer-stores", "1", "--sn", "7")
 
+# round 3: --order rows (the arriving plane consumed by source row, row groups fenced), --pack (v_pk_fma_f32 on pairs of x points, odd pairs
+# assembled from DPP moves) and --pin (partial sums used where they are updated, so that the compiler cannot sink the FMA chains)
+_add("3d7_fp32_s2_rows_packed", 3, "t3_star", "--dtype", "fp32", "--step", "2", "--sn", "16", "--prefetch", "--order", "rows")
+_add("3d7_fp32_s3_rows_packed_pd2", 3, "t3_star", "--dtype", "fp32", "--step", "3", "--sn", "16", "--prefetch", "--prefetch-depth", "2", "--order", "rows", "--bx", "32", "--by", "16", "--block-merge-y", "2")
+_add("3d7_fp32_s3_rows_unpacked", 3, "t3_star", "--dtype", "fp32", "--step", "3", "--sn", "16", "--prefetch", "--order", "rows", "--pack", "0", "--bx", "32", "--by", "16", "--block-merge-y", "2")
+_add("3d7_fp64_s2_rows", 3, "t3_star", "--dtype", "fp64", "--step", "2", "--sn", "16", "--order", "rows")
+_add("3d7_fp32_s1_rows_oddN", 3, "t3_star_odd", "--dtype", "fp32", "--order", "rows")
+_add("3d7_fp32_s2_rows_lds_nofence", 3, "t3_star", "--dtype", "fp32", "--step", "2", "--sn", "9", "--xrim", "lds", "--order", "rows", "--row-fence", "-1")
+_add("3d9x_fp32_rows", 3, "t3_cross", "--dtype", "fp32", "--dist", "2", "--schedule", "scatter", "--order", "rows")
+_add("3dodd_fp32_s2_rows", 3, "t3_odd", "--dtype", "fp32", "--step", "2", "--order", "rows")
+_add("3d_ahead_fp32_rows", 3, "t3_ahead", "--dtype", "fp32", "--sn", "8", "--order", "rows", "--prefetch")
+_add("3d7_fp32_t2_rows", 3, "t3_star", "--dtype", "fp32", "--step", "2", "--temporal", "1", "--by", "8", "--block-merge-y", "4", "--sn", "16", "--prefetch", "--order", "rows")
+_add("2d25_fp32_tile_rows", 2, "t2_box25", "--dtype", "fp32", "--order", "rows")
+_add("2d25_fp64_stream_rows", 2, "t2_box25", "--dtype", "fp64", "--streaming", "--prefetch", "--order", "rows")
+_add("2d9b_fp32_s2_rows", 2, "t2_box9", "--dtype", "fp32", "--step", "2", "--order", "rows")
+_add("2d_ahead_fp32_stream_rows", 2, "t2_ahead", "--dtype", "fp32", "--streaming", "--sn", "32", "--order", "rows")
+_add("3d7_fp32_s2_pinned_taps", 3, "t3_star", "--dtype", "fp32", "--step", "2", "--sn", "16", "--prefetch", "--prefetch-depth", "3", "--pin", "1", "--cc-opt", "-fno-slp-vectorize")
+_add("3d7_fp64_s3_pinned_taps", 3, "t3_star", "--dtype", "fp64", "--step", "3", "--sn", "16", "--pin", "1")
+
 # --stage dma (round 2): planes staged by LDS-DMA (global_load_lds_dwordx4) into the per-lane-dense LDS image, tile-edge lanes re-reading
 # from the halo regions; every schedule, both x-rim paths, box corners, wide halos (hx > points per lane), ragged grids
 _add("3d7_fp64_dma", 3, "t3_star", "--dtype", "fp64", "--stage", "dma", "--sn", "8")
@@ -112,7 +131,7 @@ _add("2d25_fp64_t2_tile", 2, "t2_box25", "--dtype", "fp64", "--step", "2", "--te
 # where the generator's drift estimate stays within the bar for the spec's iterations and the fused kernel otherwise, `--temporal force`
 # emits them regardless.  t3_star_it100 asks for 100 iterations: the forced pipelines measure the drift (they are where 1e-6 breaks), the
 # unforced one must come back as the fused kernel and stay bit-exact for all 100.
-_TM2 = ["--3d", "--dtype", "fp32", "--step", "2", "--by", "8", "--block-merge-y", "4", "--sn", "16", "--prefetch"]
+_TM2 = ["--3d", "--dtype", "fp32", "--step", "2", "--by", "8", "--block-merge-y", "2", "--sn", "16", "--prefetch"]
 _TM3 = ["--3d", "--dtype", "fp32", "--step", "3", "--bx", "34", "--by", "15", "--block-merge-y", "2", "--sn", "16", "--prefetch"]
 TEMPORAL_MARGIN = [
     ("t2_fp32_it100_forced", 3, stc("t3_star_it100"), _TM2 + ["--temporal", "force"]),

@@ -58,6 +58,17 @@ VARIANTS = [
     ("2d_stream_step3_dpp", 2, "STAR2", (1, 75, 530), ["--dtype", "fp64", "--streaming", "--prefetch", "--xrim", "dpp", "--sn", "16", "--step", "3"]),
     ("2d25_tile_fp64", 2, "BOX25", (1, 61, 268), ["--dtype", "fp64"]),
     ("2d25_stream_step2", 2, "BOX25", (1, 61, 268), ["--dtype", "fp32", "--streaming", "--sn", "9", "--step", "2", "--prefetch"]),
+    # round 3: --order rows (plane consumed by source row), packed pairs (float2 halves of the accumulator vectors), pinned sums
+    ("3d_s2_rows_packed", 3, "STAR3", (17, 21, 300), ["--3d", "--dtype", "fp32", "--sn", "6", "--step", "2", "--prefetch", "--order", "rows"]),
+    ("3d_s3_rows_packed_pd2", 3, "STAR3", (19, 23, 260), ["--3d", "--dtype", "fp32", "--sn", "8", "--step", "3", "--prefetch", "--prefetch-depth", "2", "--order", "rows", "--bx", "32", "--by", "4", "--block-merge-y", "2"]),
+    ("3d_s1_rows_oddN_scalar", 3, "STAR3", (12, 17, 263), ["--3d", "--dtype", "fp32", "--sn", "8", "--order", "rows"]),
+    ("3d_s2_rows_fp64", 3, "STAR3", (15, 19, 140), ["--3d", "--dtype", "fp64", "--sn", "5", "--step", "2", "--order", "rows"]),
+    ("3d_cross_rows", 3, "CROSS3", (14, 19, 136), ["--3d", "--dtype", "fp32", "--dist", "2", "--schedule", "scatter", "--order", "rows"]),
+    ("2d25_tile_rows", 2, "BOX25", (1, 61, 268), ["--dtype", "fp32", "--order", "rows"]),
+    ("2d25_stream_rows_s2", 2, "BOX25", (1, 61, 268), ["--dtype", "fp32", "--streaming", "--sn", "9", "--step", "2", "--prefetch", "--order", "rows"]),
+    ("3d_s2_rows_lds_rim", 3, "STAR3", (17, 21, 300), ["--3d", "--dtype", "fp32", "--sn", "6", "--step", "2", "--xrim", "lds", "--order", "rows"]),
+    ("3d_s2_rows_two_points_per_lane", 3, "STAR3", (17, 21, 300), ["--3d", "--dtype", "fp32", "--sn", "6", "--step", "2", "--order", "rows", "--bx", "16", "--block-merge-x", "2", "--by", "4", "--block-merge-y", "3"]),
+    ("3d_s2_taps_pinned", 3, "STAR3", (17, 21, 300), ["--3d", "--dtype", "fp32", "--sn", "6", "--step", "2", "--prefetch", "--pin", "1"]),
     ("2d_refdefaults", 2, "BOX9", (1, 41, 70), ["--dtype", "fp64", "--ref-defaults"]),
     ("3d_step2_prefetch_depth2", 3, "STAR3", (23, 21, 300), ["--3d", "--dtype", "fp32", "--sn", "7", "--step", "2", "--prefetch", "--prefetch-depth", "2"]),
     ("3d_step1_prefetch_depth3", 3, "STAR3", (19, 23, 270), ["--3d", "--dtype", "fp64", "--sn", "5", "--prefetch", "--prefetch-depth", "3", "--xrim", "lds"]),
