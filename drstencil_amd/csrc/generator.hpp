@@ -91,6 +91,9 @@ MI355X options:
 --pin <0|1>             Pass every partial sum through an empty asm statement where it is updated, so that the compiler cannot
                         sink the FMA chains of the unrolled streaming loop down to the store (which keeps `Range` planes of
                         source windows alive instead of the sums; default: 1 with --order rows, else 0).
+--rot-mod <n>           Scatter schedule: the partial sums rotate through n >= Range register sets (default Range).  The streaming
+                        loop is unrolled by lcm(n, LDS slots, prefetch sets): e.g. Range 7 -> 14 plane bodies, --rot-mod 8 -> 8
+                        (code size; the instruction cache holds 64 KB).
 --row-fence <mask>      sched_barrier mask between row groups (0 default: nothing crosses; -1: no fence).
 --temporal <0|1|force>  With --step n > 1: run the one-step stencil n times on chip (temporal blocking,
                         intermediate planes never leave the CU) instead of the fused stencil.  On-chip stages
@@ -178,6 +181,7 @@ inline GenResult generate(const std::vector<std::string> &args /* argv[1..] */) 
         else if (a == "--order") { if (!str_opt(o.order)) break; }
         else if (a == "--pack") { if (!int_opt(o.pack, nullptr)) break; }
         else if (a == "--row-fence") { if (!int_opt(o.row_fence, nullptr)) break; }
+        else if (a == "--rot-mod") { if (!int_opt(o.rot_mod, nullptr)) break; }
         else if (a == "--pin") { if (!int_opt(o.pin, nullptr)) break; }
         else if (a == "--exact-y") { if (!int_opt(o.exact_y, nullptr)) break; }
         else if (a == "--exact-x") { if (!int_opt(o.exact_x, nullptr)) break; }

@@ -130,6 +130,9 @@ struct GenOptions {
     int pack = -1;               // --order rows, fp32: sums of two adjacent x points as float2 halves of the accumulator vectors and
                                  // __builtin_elementwise_fma on float2 operands -> v_pk_fma_f32 (two FMAs per lane and issue slot; each half is an
                                  // IEEE fma, so results stay bit-identical).  Pairs that start at an odd column are assembled from DPP moves.  -1 auto
+    int rot_mod = 0;             // scatter schedule: register sets the partial sums rotate through (0 / < Range: Range).  A larger modulus costs
+                                 // points-per-lane registers per extra set and can shrink the unroll lcm(modulus, LDS slots, prefetch sets) -- and with
+                                 // it the code size: 14 -> 8 plane bodies for Range 7 with --rot-mod 8 (the instruction cache holds 64 KB)
     int pin = -1;                // 1: every partial sum a plane iteration (taps) / a row group (rows) has updated is passed through an empty
                                  // `asm volatile("" : "+v"(sum))` at its end.  Without it LLVM SINKS the FMA chains of the unrolled loop down to
                                  // the block that stores the finished plane -- the chain of an output spans `Range` unrolled iterations and has no

@@ -63,13 +63,23 @@ elem_bytes = 4
 
 
 def _unpack(spaceVector):
-    """15-element vectors (round 1, the reference's layout + our suffix fields) mean --schedule scatter."""
+    """15-element vectors (round 1, the reference's layout + our suffix fields) mean --schedule scatter; 16-element ones (round 2)
+    the round-2 emission (`taps`).  The 17th element (round 3) is the emission: taps | pin (taps order, partial sums pinned) |
+    rows (plane consumed by source row, pinned) | rowspk (rows + v_pk_fma_f32 pairs)."""
     v = tuple(spaceVector)
-    return v if len(v) == 16 else v + ("scatter",)
+    if len(v) == 15:
+        v = v + ("scatter",)
+    return v if len(v) == 17 else v + ("taps",)
 
 
 def FilterParams(spaceVector):
-    step, dist, blockSize, sn, s_unroll, blockMergeX, mergeFactorX, blockMergeY, mergeFactorY, m_threshold, prefetch, xrim, temporal, xcd, streaming, schedule = _unpack(spaceVector)
+    step, dist, blockSize, sn, s_unroll, blockMergeX, mergeFactorX, blockMergeY, mergeFactorY, m_threshold, prefetch, xrim, temporal, xcd, streaming, schedule, emit = _unpack(spaceVector)
+    if emit not in ("taps", "pin", "rows", "rowspk"):
+        return False
+    if emit in ("rows", "rowspk") and (schedule != "scatter" or not blockMergeY and mergeFactorY > 1):
+        return False              # --order rows: scatter schedule, block y merging
+    if emit == "rowspk" and elem_bytes != 4:
+        return False              # packed pairs are fp32
     halo = step * order
     tx = mergeFactorX * blockSize[0]
     ty = 1 if streaming else mergeFactorY * blockSize[1]
@@ -122,7 +132,7 @@ def FilterParams(spaceVector):
 class Cfg:
     """A space vector with names.  The reference addresses its vector by position (benchmarks/3d7pt_star/tuning.py:38,58); here
     one record feeds both renderings below, so the option list and the name scheme cannot drift apart."""
-    FIELDS = ("step", "dist", "block", "sn", "unroll", "block_x", "mx", "block_y", "my", "merge_forward", "prefetch", "xrim", "temporal", "xcd", "streaming", "schedule")
+    FIELDS = ("step", "dist", "block", "sn", "unroll", "block_x", "mx", "block_y", "my", "merge_forward", "prefetch", "xrim", "temporal", "xcd", "streaming", "schedule", "emit")
 
     def __init__(self, spaceVector):
         for k, v in zip(self.FIELDS, _unpack(spaceVector)):
@@ -150,6 +160,10 @@ _PIECES = [
     # --dist is always on the command line (reference scheme) and alone selects the reuse schedule: scatter is spelled out
     ("--schedule scatter",                             "",                   lambda c: (),                           lambda c: c.schedule == "scatter"),
     ("",                                               "r",                  lambda c: (),                           lambda c: c.schedule == "reuse"),
+    # round 3: the emitter bounds live ranges itself (profiles/r03_sinking.md)
+    ("--pin 1",                                        "k",                  lambda c: (),                           lambda c: c.emit == "pin"),
+    ("--order rows --pack 0",                          "o",                  lambda c: (),                           lambda c: c.emit == "rows"),
+    ("--order rows --pack 1",                          "ok",                 lambda c: (),                           lambda c: c.emit == "rowspk"),
 ]
 _NAME_ORDER = (1, 0) + tuple(range(2, len(_PIECES)))      # the name leads with fu<step>d<dist>, the command line with the block shape
 
@@ -164,7 +178,7 @@ def cfgToString(spaceVector):
     return "".join(_PIECES[i][1].format(*_PIECES[i][2](c)) for i in _NAME_ORDER if _PIECES[i][3](c))
 
 
-def enumerate_space(steps=(1,), full=False):
+def enumerate_space(steps=(1,), full=False, emits=("taps",)):
     """The sweep space.  Lane counts include non-powers of two: with temporal blocking a tile owns
     mx*bx - 2*roundup((step-1)*order, mx) columns, so e.g. bx = 66 (264 columns, 256 owned) tiles a
     1024-wide grid exactly where bx = 64 would need a fifth tile."""
@@ -206,11 +220,12 @@ def enumerate_space(steps=(1,), full=False):
         if ndim == 2 and v[14]:
             if v[2][1] != 1 or v[8] != 1:
                 continue           # 2D --streaming ignores by / y merging (codegen_2d.hpp:125)
-        cands = [tuple(v) + ("scatter",)]
+        cands = [tuple(v) + ("scatter", e) for e in emits]
         # the reference sweeps dist over its legal range (tuning.py:110-112): each value is a different split between
         # resident source planes and carried partial sums (--schedule reuse)
         for d in range(max(1, (v[0] - 1) * order), v[0] * order + 1):
-            cands.append(tuple(v[:1] + [d] + v[2:]) + ("reuse",))
+            if "taps" in emits:
+                cands.append(tuple(v[:1] + [d] + v[2:]) + ("reuse", "taps"))
         for c in cands:
             if FilterParams(c):
                 out.append(c)
@@ -535,13 +550,14 @@ def main():
     ap.add_argument("--configs-file", default=None, help="file with one raw option string per line instead of the space")
     ap.add_argument("--profile-top", type=int, default=0, help="after the search: rocprofv3 counters of the best N configurations -> <out>/gpuMetrics.csv (reference flow)")
     ap.add_argument("--jobs", type=int, default=16, help="compile workers")
+    ap.add_argument("--emit", default="taps", help="comma-separated emissions to sweep: taps (rounds 1-2), pin, rows, rowspk (round 3)")
     ap.add_argument("--extra", default="", help="generator options added to every configuration (e.g. \"--cc-opt -fno-slp-vectorize\")")
     a = ap.parse_args()
     order, ndim, elem_bytes = a.order, (3 if a.is3d else 2), (4 if a.dtype == "fp32" else 8)
     if a.configs_file:
         paras = [l.strip() for l in open(a.configs_file) if l.strip() and not l.startswith("#")]
     else:
-        paras = enumerate_space(tuple(int(s) for s in a.steps.split(",")))
+        paras = enumerate_space(tuple(int(s) for s in a.steps.split(",")), emits=tuple(a.emit.split(",")))
         random.seed(a.seed)
         random.shuffle(paras)
         if a.max_configs:
