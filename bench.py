@@ -113,6 +113,24 @@ WINDOW2WG = {
     "c4": ["--3d", "--dtype", "fp32", "--step", "2", "--schedule", "window", "--prefetch", "--prefetch-depth", "1", "--waves-per-eu", "4", "--bx", "32", "--by", "16",
            "--block-merge-x", "4", "--block-merge-y", "2", "--sn", "8", "--xcd-remap", "2", "--cc-opt", "-fno-slp-vectorize"],
 }
+# round 3: three time steps per launch with the reference's own --step 3 arithmetic (algebraically fused 63-point stencil, one pass), BIT-IDENTICAL
+# to the oracle.  It fits because the emitter now owns its register allocation (--order rows: the arriving plane is consumed by source row;
+# partial sums pinned where they are updated so that LLVM cannot sink the FMA chains and keep 7 planes of source windows alive -- 256 VGPRs +
+# scratch before, 98-104 now, profiles/r03_sinking.md): two 512-lane workgroups per CU.  Best of a 1248-configuration grid and a 900-configuration
+# random sweep (profiles/r03_tune_c4_s3_rows_grid.txt: 1.584 ms = 1998 GStencil/s on that box; 1.547 ms on another, 1.92 on the slowest one seen:
+# these VALU-dense kernels vary far more from device to device than the memory-bound step-2 headline), so a few candidates are timed on the
+# device at hand and the fastest one is reported -- what the tuner does, in miniature.  Side measurement: the headline and the roofline stay
+# with the step-2 kernel (>= 0.70 of the HBM peak).
+_S3 = ["--3d", "--dtype", "fp32", "--step", "3", "--prefetch", "--prefetch-depth", "1", "--block-merge-x", "4", "--order", "rows", "--pack", "0", "--cc-opt", "-fno-slp-vectorize"]
+FUSED3 = {
+    "c4": [_S3 + ["--bx", "64", "--by", "8", "--block-merge-y", "2", "--sn", "64", "--xcd-remap", "2"],
+           _S3 + ["--bx", "128", "--by", "4", "--block-merge-y", "2", "--sn", "128", "--xcd-remap", "2"],
+           _S3 + ["--bx", "64", "--by", "16", "--block-merge-y", "1", "--sn", "128", "--xcd-remap", "2"],      # one 1024-lane workgroup per CU: every CU on the same stream block
+           _S3 + ["--bx", "32", "--by", "16", "--block-merge-y", "2", "--sn", "64", "--xcd-remap", "0"]],
+    "c3": [_S3 + ["--bx", "64", "--by", "8", "--block-merge-y", "2", "--sn", "64", "--xcd-remap", "1"],
+           _S3 + ["--bx", "32", "--by", "16", "--block-merge-y", "2", "--sn", "32", "--xcd-remap", "2"],
+           _S3 + ["--bx", "16", "--by", "16", "--block-merge-y", "2", "--sn", "64", "--xcd-remap", "2"]],
+}
 # N > 1 (z slabs of C4): the same fused kernel; slabs of 256 planes or fewer get 16-plane stream blocks.  One stream block
 # per tile (256 tiles = one workgroup per CU) is the fastest way to sweep a slab ALONE (128-plane view 0.186 ms vs 0.199,
 # 256: 0.380 vs 0.424, 512: 0.758 vs 0.804 -- profiles/r01_exp_r1zj_one_block_per_tile.log, r01_exp_r1zk_...), but its
@@ -147,6 +165,7 @@ def kernels():
     out += [("bench_%s_step1" % w, w, STEP1[w]) for w in sorted(STEP1)]
     out += [("bench_%s_temporal2" % w, w, TEMPORAL2[w]) for w in sorted(TEMPORAL2)]
     out += [("bench_%s_window_two_workgroups" % w, w, WINDOW2WG[w]) for w in sorted(WINDOW2WG)]
+    out += [("bench_%s_fused3_%d" % (w, i), w, o) for w in sorted(FUSED3) for i, o in enumerate(FUSED3[w])]
     return out
 
 
@@ -474,11 +493,17 @@ def main(argv=None):
         else:
             M *= pworld
     kern1 = kernf = kernw = None
+    kern3 = []
     if pworld == 1:
         kern = drs.Kernel(opts + [w["stc"]])
         if args.workload in STEP1 and not args.kernel_args and not args.headline_only:
             kern1 = drs.Kernel(STEP1[args.workload] + [w["stc"]])
             kernf = drs.Kernel(TEMPORAL2[args.workload] + [w["stc"]])
+            for o3 in FUSED3.get(args.workload, []):
+                try:
+                    kern3.append((drs.Kernel(o3 + [w["stc"]]), o3))
+                except drs.KernelBuildError:          # a compiler that needs scratch for it: not a candidate
+                    pass
             if args.workload in WINDOW2WG:
                 try:
                     kernw = drs.Kernel(WINDOW2WG[args.workload] + [w["stc"]])
@@ -572,6 +597,24 @@ def main(argv=None):
         step1 = side(kern1, STEP1[args.workload], 16) if kern1 is not None else None
         fused2 = side(kernf, TEMPORAL2[args.workload], 32) if kernf is not None else None
         window2 = side(kernw, WINDOW2WG[args.workload], 32) if kernw is not None else None
+        fused3 = None
+        if kern3:
+            # every candidate timed on THIS device (they differ by up to 20 % from device to device), the fastest reported in full
+            cands = [(side(k3, o3, 24), k3) for k3, o3 in kern3]
+            best3, kbest = max(cands, key=lambda c: c[0]["GStencil_per_s"])
+            fused3 = dict(best3)
+            fused3["candidates_timed_on_this_device"] = [{"generator_options": c["generator_options"], "avg_launch_ms": c["avg_launch_ms"], "GStencil_per_s": c["GStencil_per_s"]} for c, _ in cands]
+            fused3["vgprs"], fused3["scratch_bytes_per_lane"] = kbest.resources.get("vgprs"), kbest.resources.get("scratch_bytes_per_lane")
+            if not args.no_verify:      # one launch against the emitted gold kernel on the whole grid: bit for bit
+                G3 = torch.zeros_like(A)
+                g3 = torch.Generator(device=dev).manual_seed(1)
+                A.copy_(torch.rand(shape, dtype=tdt, device=dev, generator=g3))      # fresh input: the timing loops have long overflowed the old one
+                B.zero_()
+                kbest.launch(A.data_ptr(), B.data_ptr())
+                kbest.launch_gold(A.data_ptr(), G3.data_ptr())
+                torch.cuda.synchronize()
+                fused3["verified_vs_gold_kernel_full_grid_bit_exact"] = bool(torch.equal(B, G3))
+                del G3
         verified, verification, host_slab, first_out = None, None, None, None
         if not args.no_verify:
             g = torch.Generator(device=dev).manual_seed(1)
@@ -617,7 +660,7 @@ def main(argv=None):
         kinfo = sweep.kernel(run.plan.interior[1] - run.plan.interior[0]).info
         kres = sweep.kernel(run.plan.interior[1] - run.plan.interior[0]).resources
         parallelism = "%s-slab x%d%s, RCCL send/recv halo every %d launch(es), overlapped" % ("z" if w["ndim"] == 3 else "y", pworld, " (weak: grid %s)" % "x".join(str(d) for d in ((L, M, N) if w["ndim"] == 3 else (M, N))) if weak else "", args.exchange_every)
-        step1 = fused2 = window2 = None
+        step1 = fused2 = window2 = fused3 = None
         verified, verification, host_slab, first_out = None, None, None, None     # the slab kernels' parity is tests/test_gpu_parity.py::test_c4_slab_views_at_full_size
         if not args.no_verify and not rehearse:      # (a rehearsal's self-neighbour exchange is not the physical one)
             verified, verification = verify_slab_run(torch, dist, run, sweep, (L, M, N) if w["ndim"] == 3 else (M, N), H, launches_per_step, iters, prank, pworld, dev, tdt)
@@ -659,6 +702,9 @@ def main(argv=None):
             out["config"]["exchange_calibration"] = calibration      # measured on this machine during warm-up (multigpu.measure_exchange_every)
         out["step1_kernel"] = step1                 # one time step per launch: highest roofline fraction
         out["temporal_step2_kernel"] = fused2       # on-chip temporal blocking (2 stages): equal to the headline up to rounding
+        out["fused_step3_kernel"] = fused3          # three time steps per launch, the reference's --step 3 arithmetic bit for bit (round 3)
+        if fused3:
+            out["best_bit_exact_GStencil_per_s"] = max(value, fused3["GStencil_per_s"])
         out["two_workgroups_per_cu_kernel"] = window2   # the same fused arithmetic from rotating register windows at 126 VGPRs: two workgroups per CU
         if not args.no_cpu_baseline and pworld == 1:
             sys.path.insert(0, ROOT)
