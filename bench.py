@@ -70,7 +70,9 @@ TUNED = {
     # 2D one-shot LDS tiles (BASELINE C2 "no temporal blocking (baseline LDS tile)", C5 "wide-halo LDS staging"): best of the
     # exhaustive 2D searches, profiles/r01_tune_c2_exhaustive.txt / r01_tune_c5_exhaustive.txt (0.78 of the HBM peak each)
     "c2": ["--dtype", "fp32", "--bx", "128", "--by", "2", "--block-merge-x", "4", "--block-merge-y", "2", "--xcd-remap", "0"],
-    "c5": ["--dtype", "fp64", "--bx", "64", "--by", "4", "--block-merge-x", "2", "--block-merge-y", "4", "--xcd-remap", "0"],
+    # round 3: the tile consumed by source row (--order rows: the row's own vector + DPP neighbours just before its FMAs, sums pinned), 8 rows per
+    # lane: 0.694 ms against 0.717 for round 2's kernel in the same process (profiles/r03_exp_r3d.log), bit-identical
+    "c5": ["--dtype", "fp64", "--bx", "64", "--by", "4", "--block-merge-x", "2", "--block-merge-y", "8", "--xcd-remap", "0", "--order", "rows"],
     # fp64 (profiles/r01_tune_shipped.md: exhaustive searches at the reference sizes): the 2D tile of 2d5pt_star step 1; fused step 2 in 3D
     "c2f64": ["--dtype", "fp64", "--bx", "128", "--by", "4", "--block-merge-x", "2", "--block-merge-y", "2", "--xcd-remap", "0"],
     # round 2: a tuner run over the space with the reference's dist dimension put a reuse-schedule kernel (32x8 lanes, --dist 2) 2 % ahead on
@@ -87,11 +89,14 @@ TUNED = {
     "s_2d9pt_cross": ["--dtype", "fp64", "--step", "2", "--dist", "2", "--bx", "64", "--by", "4", "--block-merge-x", "2", "--block-merge-y", "4", "--xcd-remap", "0"],
     # the wide stencils (order 2 / 35 fused taps) are fastest as on-chip temporal pipelines; in fp64 those stay within 1e-12 of the fused
     # arithmetic (measured 1.7e-15), the bar the tests and bench.py's verification hold fp64 temporal kernels to
-    "s_2d9pt_star": ["--dtype", "fp64", "--step", "2", "--dist", "4", "--temporal", "1", "--bx", "66", "--by", "15", "--block-merge-x", "2", "--block-merge-y", "2", "--xcd-remap", "0"],
+    # round 3: with the emitter in charge of the registers the FUSED (bit-exact) step-2 kernels of 2d9pt_star and 3d9pt_cross are faster than
+    # round 2's temporal pipelines (749 vs 722 and 665 vs 611 GStencil/s in one process, profiles/r03_exp_r3d.log); 2d25pt_box step 2 (81 fp64
+    # taps) stays a pipeline (574 vs 519)
+    "s_2d9pt_star": ["--dtype", "fp64", "--step", "2", "--bx", "64", "--by", "4", "--block-merge-x", "2", "--block-merge-y", "4", "--xcd-remap", "0", "--order", "rows"],
     "s_2d25pt_box": ["--dtype", "fp64", "--step", "2", "--dist", "4", "--temporal", "1", "--streaming", "--prefetch", "--prefetch-depth", "1", "--bx", "128", "--by", "1",
                      "--block-merge-x", "2", "--cyclic-merge-y", "1", "--sn", "32", "--xcd-remap", "0"],
-    "s_3d9pt_cross": ["--3d", "--dtype", "fp64", "--step", "2", "--dist", "2", "--temporal", "1", "--prefetch", "--prefetch-depth", "1", "--bx", "34", "--by", "15",
-                      "--block-merge-x", "2", "--block-merge-y", "2", "--sn", "64", "--xcd-remap", "0"],
+    "s_3d9pt_cross": ["--3d", "--dtype", "fp64", "--step", "2", "--schedule", "scatter", "--prefetch", "--prefetch-depth", "1", "--bx", "32", "--by", "16",
+                      "--block-merge-x", "2", "--block-merge-y", "2", "--sn", "32", "--xcd-remap", "2", "--order", "rows"],
 }
 # the same workloads with one time step per launch: highest roofline fraction.  Full-row tiles (256 lanes x 4
 # points = N), 2 lane rows x 4 rows, 4-plane stream blocks, prefetch: the optimum of the exhaustive 1520-configuration
@@ -127,6 +132,9 @@ FUSED3 = {
            _S3 + ["--bx", "128", "--by", "4", "--block-merge-y", "2", "--sn", "128", "--xcd-remap", "2"],
            _S3 + ["--bx", "64", "--by", "16", "--block-merge-y", "1", "--sn", "128", "--xcd-remap", "2"],      # one 1024-lane workgroup per CU: every CU on the same stream block
            _S3 + ["--bx", "32", "--by", "16", "--block-merge-y", "2", "--sn", "64", "--xcd-remap", "0"]],
+    # C2 (2d5pt_star 8192^2 fp32, one-shot LDS tiles): the fused 25-point (step 3) and 41-point (step 4) stencils, 2166 / 2732 GStencil/s bit-exact
+    "c2": [["--dtype", "fp32", "--step", "4", "--bx", "128", "--by", "4", "--block-merge-x", "4", "--block-merge-y", "4", "--xcd-remap", "0", "--order", "rows", "--pack", "0"],
+           ["--dtype", "fp32", "--step", "3", "--bx", "128", "--by", "4", "--block-merge-x", "4", "--block-merge-y", "4", "--xcd-remap", "0", "--order", "rows", "--pack", "0"]],
     "c3": [_S3 + ["--bx", "64", "--by", "8", "--block-merge-y", "2", "--sn", "64", "--xcd-remap", "1"],
            _S3 + ["--bx", "32", "--by", "16", "--block-merge-y", "2", "--sn", "32", "--xcd-remap", "2"],
            _S3 + ["--bx", "16", "--by", "16", "--block-merge-y", "2", "--sn", "64", "--xcd-remap", "2"]],
@@ -195,6 +203,12 @@ def cpu_baseline(workload, step, budget_s=4.0, host_slab=None, gpu_first_launch=
     import numpy as np
     import oracle
     w = WORKLOADS[workload]
+    # as many OpenMP threads as this process may really run on: the GPU box's host reports 128 hardware threads, the container's
+    # CPU quota may be 16 -- 128 threads on that quota spend most of their time throttled (round 3, first run: 2.3 GStencil/s)
+    host_threads = oracle.threads()
+    usable = oracle.usable_cpus()
+    if usable < host_threads:
+        oracle.set_threads(usable)
     spec = oracle.Spec(w["stc"], w["ndim"], step)
     L, M, N = spec.dims
     dt = np.float32 if w["dtype"] == "fp32" else np.float64
@@ -253,8 +267,9 @@ def cpu_baseline(workload, step, budget_s=4.0, host_slab=None, gpu_first_launch=
             break
     gst = sweeps * step * interior / el / 1e9
     return dict(value=gst, unit="GStencil/s", cores=oracle.threads(), kind="port", isa=oracle.isa(),
-                sample="%s, %d sweeps in %.1f s (OpenMP, %d threads, %s clone of the sweep, arrays first-touched by the team)"
-                       % (sample, sweeps, el, oracle.threads(), oracle.isa())), check
+                host_hardware_threads=host_threads,
+                sample="%s, %d sweeps in %.1f s (OpenMP, %d threads = the CPUs this process may use of the host's %d, %s clone of the sweep, arrays first-touched by the team)"
+                       % (sample, sweeps, el, oracle.threads(), host_threads, oracle.isa())), check
 
 
 def verify_timed_kernel(torch, kern, workload, A, B, temporal):
@@ -499,6 +514,7 @@ def main(argv=None):
         if args.workload in STEP1 and not args.kernel_args and not args.headline_only:
             kern1 = drs.Kernel(STEP1[args.workload] + [w["stc"]])
             kernf = drs.Kernel(TEMPORAL2[args.workload] + [w["stc"]])
+        if not args.kernel_args and not args.headline_only:
             for o3 in FUSED3.get(args.workload, []):
                 try:
                     kern3.append((drs.Kernel(o3 + [w["stc"]]), o3))
@@ -590,7 +606,7 @@ def main(argv=None):
             else:
                 n1, ms1 = k.run_timed(A.data_ptr(), B.data_ptr(), iterations=iters, warmup=4, stream=stream.cuda_stream)
             by = k.bytes_per_launch()
-            return {"generator_options": " ".join(o), "arithmetic": k.info.get("arithmetic"), "tolerance_horizon_iterations": k.info.get("tolerance_horizon_iterations"),
+            return {"generator_options": " ".join(o), "step": k.info["step"], "arithmetic": k.info.get("arithmetic"), "tolerance_horizon_iterations": k.info.get("tolerance_horizon_iterations"),
                     "GStencil_per_s": k.updates_per_launch() * n1 / (ms1 * 1e-3) / 1e9,
                     "avg_launch_ms": ms1 / n1, "achieved_GBps": by * n1 / (ms1 * 1e-3) / 1e9,
                     "roofline_frac": by * n1 / (ms1 * 1e-3) / 1e9 / HBM_PEAK_GBS}
@@ -702,7 +718,9 @@ def main(argv=None):
             out["config"]["exchange_calibration"] = calibration      # measured on this machine during warm-up (multigpu.measure_exchange_every)
         out["step1_kernel"] = step1                 # one time step per launch: highest roofline fraction
         out["temporal_step2_kernel"] = fused2       # on-chip temporal blocking (2 stages): equal to the headline up to rounding
-        out["fused_step3_kernel"] = fused3          # three time steps per launch, the reference's --step 3 arithmetic bit for bit (round 3)
+        # round 3: several time steps per launch with the reference's own fused --step n arithmetic, bit for bit (C3 / C4: --step 3, C2: --step 4)
+        out["fused_multistep_kernel"] = fused3
+        out["fused_step3_kernel"] = fused3 if (fused3 and fused3["step"] == 3) else None
         if fused3:
             out["best_bit_exact_GStencil_per_s"] = max(value, fused3["GStencil_per_s"])
         out["two_workgroups_per_cu_kernel"] = window2   # the same fused arithmetic from rotating register windows at 126 VGPRs: two workgroups per CU

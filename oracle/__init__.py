@@ -46,6 +46,7 @@ def lib():
         for n in ("drso_copy_f64", "drso_copy_f32"):
             getattr(L, n).argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
         L.drso_isa.restype = ctypes.c_char_p
+        L.drso_set_threads.argtypes = [ctypes.c_int]
         _LIB = L
     return _LIB
 
@@ -140,6 +141,31 @@ def check(spec, out, ref):
 
 def threads():
     return lib().drso_threads()
+
+
+def usable_cpus():
+    """CPUs this process may really use: the affinity mask, capped by the cgroup CPU quota (a container limited to 16 CPUs on a
+    128-thread host still reports 128 to OpenMP)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(int(txt[0]) / int(txt[1]) + 0.5)))
+            else:
+                q = int(txt[0])
+                if q > 0:
+                    per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                    n = min(n, max(1, int(q / per + 0.5)))
+            break
+        except Exception:
+            continue
+    return n
+
+
+def set_threads(n):
+    lib().drso_set_threads(int(n))
 
 
 def isa():

@@ -361,6 +361,16 @@ const char *drso_isa(void)
 #endif
     return "baseline";
 }
+/* bench.py's cpu_baseline: use as many threads as this process may really run on (a container's CPU quota is not visible to
+ * omp_get_max_threads(): 128 threads on a 16-CPU quota spend their time throttled) */
+void drso_set_threads(int n)
+{
+#ifdef _OPENMP
+    if (n > 0) omp_set_num_threads(n);
+#else
+    (void)n;
+#endif
+}
 int drso_threads(void)
 {
 #ifdef _OPENMP

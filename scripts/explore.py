@@ -43,9 +43,14 @@ def main():
         d = [int(x) for x in dims.split()]
         if ndim == 2:
             d = [1] + d
-        stc = os.path.join(outdir, "x%s_%s.stc" % (pts, "x".join(str(x) for x in d)))
+        stc = os.path.join(outdir, "x%s_%s.stc" % (pts.lstrip("@"), "x".join(str(x) for x in d)))
         if not os.path.exists(stc):
-            write_stc(stc, ndim, tuple(d), 4, PTS[pts])
+            if pts.startswith("@"):       # the point list of a shipped spec: benchmarks/<name>/<name>.stc
+                body = open(os.path.join(ROOT, "benchmarks", pts[1:], pts[1:] + ".stc")).read().split("stencil", 1)[1]
+                table = [tuple(float(x) if "." in x else int(x) for x in ln.split()) for ln in body.strip().splitlines() if ln.strip()]
+            else:
+                table = PTS[pts]
+            write_stc(stc, ndim, tuple(d), 4, table)
         args = (["--3d"] if ndim == 3 else []) + ["--dtype", dtype] + opts.split() + [stc]
         jobs.append((name, ndim, d, dtype, args))
     from concurrent.futures import ProcessPoolExecutor

@@ -340,6 +340,9 @@ def test_tuner_search_end_to_end():
     text = open(os.path.join(out, "stdout.txt")).read()
     assert "[tuner rc=0]" in text and "best:" in text, text[-1500:]
     rows = [json.loads(ln) for ln in open(os.path.join(out, "results.jsonl"))]
+    rechecked = [r for r in rows if r.get("recheck")]           # winners compared with the gold kernel again when the ranking is final
+    assert all(r["verified"] is True for r in rechecked)
+    rows = [r for r in rows if not r.get("recheck")]
     timed = [r for r in rows if r.get("duration_ns")]
     import re as _re
     m = _re.search(r"(\d+) configurations, .*?(\d+) dropped by the register model", text)
