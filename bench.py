@@ -379,6 +379,9 @@ def parse_args(argv=None):
     ap.add_argument("--exchange-every", type=int, default=0, choices=[0, 1, 2],
                     help="N > 1: launches per halo exchange (2: ghost planes twice as wide, one exchange per ping-pong pair; "
                          "0 = measured during warm-up on this machine, multigpu.measure_exchange_every)")
+    ap.add_argument("--slab-runtime", default="torch", choices=["torch", "native"],
+                    help="N > 1: torch = drstencil_amd.multigpu.SlabRun (torch.distributed send/recv; the reference implementation); native = the "
+                         "C ABI's drs_slab_* entry points (RCCL called directly, one ping-pong pair captured into a HIP graph)")
     ap.add_argument("--headline-only", action="store_true", help="skip the side measurements (profiling runs: one dr_ kernel in the trace)")
     ap.add_argument("--no-verify", action="store_true", help="skip the post-loop comparison of the timed kernel with the gold kernel and the oracle")
     ap.add_argument("--n1-value", type=float, default=None, help="N > 1: the N = 1 value of the same workload; the line then carries value / (N * n1) as efficiency_vs_n1")
@@ -530,6 +533,11 @@ def main(argv=None):
         auto_every = args.exchange_every == 0      # decided after the process group is up, from measured sweep / exchange times
         sweep = HipSweep(w["stc"], opts, os.path.join(ROOT, "drstencil_amd", "_kcache"),
                          alone_opts=None if args.kernel_args else slab_alone_options(args.workload, pworld, args.scaling == "weak"))
+        kern_n1 = None
+        if not args.kernel_args and args.scaling != "weak":
+            kern_n1 = drs.Kernel(TUNED[args.workload] + [w["stc"]])      # rank 0 measures the same box's single-GPU rate before the slab run
+        if args.slab_runtime == "native" and args.scaling == "weak":
+            raise SystemExit("bench.py: --slab-runtime native runs the spec's own grid (strong scaling)")
         for r in (range(pworld) if args.prebuild_only else (prank,)):
             for ev in ((1, 2) if auto_every else (args.exchange_every,)):      # both modes' kernels: built (cache hits) before HIP is up
                 sweep.prebuild(SlabPlan(L if w["ndim"] == 3 else M, H, pworld, r, ev))
@@ -637,10 +645,44 @@ def main(argv=None):
             A.copy_(torch.rand(shape, dtype=tdt, device=dev, generator=g))      # the input the timed loop started from
             verified, verification, host_slab, first_out = verify_timed_kernel(torch, kern, args.workload, A, B, kinfo.get("stages", 1) > 1)
     else:
+        # the N = 1 reference of THIS machine, measured by rank 0 before the slab run (VERDICT r02 item 4 iii: the driver's `bench.py
+        # --gpus N` passes no --n1-value): the single-GPU headline kernel on a scratch copy of the whole grid, same protocol as N = 1
+        n1_value = args.n1_value
+        if n1_value is None and kern_n1 is not None:
+            n1 = torch.zeros(2, dtype=torch.float64, device=dev)
+            if rank == 0:
+                shape1 = (L, M, N) if w["ndim"] == 3 else (M, N)
+                A1 = torch.rand(shape1, dtype=tdt, device=dev)
+                B1 = torch.zeros_like(A1)
+                st1 = torch.cuda.current_stream(dev)
+                tw = time.perf_counter()
+                while time.perf_counter() - tw < MIN_WARM_S:
+                    for _ in range(8):
+                        kern_n1.run(A1.data_ptr(), B1.data_ptr(), iterations=iters, stream=st1.cuda_stream)
+                    torch.cuda.synchronize()
+                n_1, ms_1 = 0, 0.0
+                for _ in range(3):
+                    a_, b_ = kern_n1.run_timed(A1.data_ptr(), B1.data_ptr(), iterations=4 * iters, warmup=0, stream=st1.cuda_stream)
+                    n_1, ms_1 = n_1 + a_, ms_1 + b_
+                n1[0] = kern_n1.updates_per_launch() * n_1 / (ms_1 * 1e-3) / 1e9
+                n1[1] = ms_1 / n_1
+                del A1, B1
+                torch.cuda.empty_cache()
+            dist.all_reduce(n1, op=dist.ReduceOp.MAX)
+            n1_value = float(n1[0])
+            n1_launch_ms = float(n1[1])
+        else:
+            n1_launch_ms = None
         if auto_every:
             args.exchange_every, calibration = measure_exchange_every(torch, dist, (L, M, N) if w["ndim"] == 3 else (M, N), H, prank, pworld, sweep, dev, tdt,
                                                                        self_neighbour=bool(rehearse))
-        run = (SelfNeighbourRun if rehearse else SlabRun)(torch, dist, (L, M, N) if w["ndim"] == 3 else (M, N), H, step, iters, prank, pworld, sweep, dev, tdt, every=args.exchange_every)
+        if args.slab_runtime == "native":
+            from drstencil_amd.multigpu import NativeSlabRun
+            run = NativeSlabRun(torch, dist, w["stc"], opts, (L, M, N) if w["ndim"] == 3 else (M, N), H, step, iters, prank, world, dev, tdt, every=args.exchange_every,
+                                alone_opts=None if args.kernel_args else slab_alone_options(args.workload, pworld, args.scaling == "weak"),
+                                rehearse_world=pworld if rehearse else 0, cache_dir=os.path.join(ROOT, "drstencil_amd", "_kcache"))
+        else:
+            run = (SelfNeighbourRun if rehearse else SlabRun)(torch, dist, (L, M, N) if w["ndim"] == 3 else (M, N), H, step, iters, prank, pworld, sweep, dev, tdt, every=args.exchange_every)
         g = torch.Generator(device=dev).manual_seed(1 + prank)
         run.A.copy_(torch.rand(run.A.shape, dtype=tdt, device=dev, generator=g))
         torch.cuda.synchronize()     # the run's streams are not the one that filled A
@@ -675,6 +717,8 @@ def main(argv=None):
         el, ev_ms = float(t[0]), float(t[1])
         kinfo = sweep.kernel(run.plan.interior[1] - run.plan.interior[0]).info
         kres = sweep.kernel(run.plan.interior[1] - run.plan.interior[0]).resources
+        if args.slab_runtime == "native":
+            calibration = dict(calibration or {}, native_runtime=run.slab.info)
         parallelism = "%s-slab x%d%s, RCCL send/recv halo every %d launch(es), overlapped" % ("z" if w["ndim"] == 3 else "y", pworld, " (weak: grid %s)" % "x".join(str(d) for d in ((L, M, N) if w["ndim"] == 3 else (M, N))) if weak else "", args.exchange_every)
         step1 = fused2 = window2 = fused3 = None
         verified, verification, host_slab, first_out = None, None, None, None     # the slab kernels' parity is tests/test_gpu_parity.py::test_c4_slab_views_at_full_size
@@ -712,8 +756,11 @@ def main(argv=None):
         }
         if pworld > 1:
             out["rank_ms_per_step"] = rank_ms_per_step
-            if args.n1_value:
-                out["efficiency_vs_n1"] = value / (pworld * args.n1_value)     # strong and weak alike: N GPUs against N times one GPU's rate
+            if n1_value:
+                # strong and weak alike: N GPUs against N times one GPU's rate (a rehearsal's value is ONE rank's share of the work)
+                out["efficiency_vs_n1"] = value / n1_value if rehearse else value / (pworld * n1_value)
+                out["n1_reference"] = {"value": n1_value, "avg_launch_ms": n1_launch_ms,
+                                       "source": "--n1-value" if args.n1_value else "measured by rank 0 on this machine before the slab run: the single-GPU headline kernel on the whole grid"}
         if calibration:
             out["config"]["exchange_calibration"] = calibration      # measured on this machine during warm-up (multigpu.measure_exchange_every)
         out["step1_kernel"] = step1                 # one time step per launch: highest roofline fraction

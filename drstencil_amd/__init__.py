@@ -61,6 +61,20 @@ def lib():
     L.drs_kernel_launch_pair.argtypes = [vp, vp, vp, vp, vp, vp]
     L.drs_kernel_run.argtypes = [vp, vp, vp, ci, ci, vp]
     L.drs_kernel_run_timed.argtypes = [vp, vp, vp, ci, ci, vp, ctypes.POINTER(ctypes.c_float)]
+    L.drs_slab_unique_id.argtypes = [vp]
+    L.drs_slab_open.restype = vp
+    L.drs_slab_open.argtypes = [ci, cpp, ci, cpp, ci, ci, ci, ci, ctypes.c_char_p, ctypes.POINTER(vp)]
+    L.drs_slab_plan.argtypes = [vp, ctypes.POINTER(ctypes.c_long * 8)]
+    L.drs_slab_connect.argtypes = [vp, vp, vp]
+    L.drs_slab_run.argtypes = [vp, vp, vp, ci]
+    L.drs_slab_sync.argtypes = [vp]
+    L.drs_slab_stream.restype = vp
+    L.drs_slab_stream.argtypes = [vp]
+    L.drs_slab_info.restype = ctypes.c_char_p
+    L.drs_slab_info.argtypes = [vp]
+    L.drs_slab_error.restype = ctypes.c_char_p
+    L.drs_slab_error.argtypes = [vp]
+    L.drs_slab_close.argtypes = [vp]
     L.drs_fill_random_f64.argtypes = [vp, ctypes.c_size_t, ctypes.c_uint]
     L.drs_fill_random_f32.argtypes = [vp, ctypes.c_size_t, ctypes.c_uint]
     for n in ("drs_check_error_f64", "drs_check_error_f32"):
@@ -78,6 +92,8 @@ EXPORTS = [
     "drs_kernel_build", "drs_kernel_close", "drs_kernel_unload", "drs_kernel_info", "drs_kernel_path", "drs_kernel_resources", "drs_kernel_launch", "drs_kernel_launch_pair",
     "drs_kernel_launch_gold", "drs_kernel_run", "drs_kernel_run_timed",
     "drs_fill_random_f64", "drs_fill_random_f32", "drs_check_error_f64", "drs_check_error_f32",
+    "drs_slab_unique_id", "drs_slab_open", "drs_slab_plan", "drs_slab_connect", "drs_slab_run", "drs_slab_sync", "drs_slab_stream", "drs_slab_info",
+    "drs_slab_error", "drs_slab_close",
 ]
 
 
@@ -254,6 +270,64 @@ class Kernel:
             h, self.h = self.h, None
             if lib().drs_kernel_unload(h) != 0:
                 raise RuntimeError("drs_kernel_unload failed")
+
+    __del__ = close
+
+
+def slab_unique_id():
+    """The 128-byte id a slab communicator is created from (rank 0 calls this and distributes the bytes)."""
+    buf = ctypes.create_string_buffer(128)
+    if lib().drs_slab_unique_id(buf) != 0:
+        raise RuntimeError("drs_slab_unique_id failed (librccl not found?)")
+    return buf.raw
+
+
+class Slab:
+    """One rank of a slab-decomposed run through the native N > 1 entry points (include/drstencil_amd.h: drs_slab_*): plan and
+    kernels in the constructor (before any GPU call), connect() once the device is set, run() on caller-owned device buffers of
+    `Lloc` planes.  multigpu.SlabRun is the torch.distributed implementation it equals bit for bit."""
+
+    def __init__(self, args, world, rank, every=1, alone_args=None, rehearse_world=0, cache_dir=None):
+        n, arr = _argv(args)
+        an, aarr = _argv(alone_args) if alone_args else (0, None)
+        log = ctypes.c_void_p()
+        self.h = lib().drs_slab_open(n, arr, an, aarr, world, rank, every, rehearse_world, os.fsencode(cache_dir) if cache_dir else None, ctypes.byref(log))
+        msg = _take(log)
+        if not self.h:
+            raise KernelBuildError(msg or "drs_slab_open failed")
+        p = (ctypes.c_long * 8)()
+        lib().drs_slab_plan(self.h, ctypes.byref(p))
+        self.lo, self.hi, self.z0, self.z1, self.Lloc, self.G, self.H, self.every = [int(x) for x in p]
+
+    def connect(self, unique_id, stream=0):
+        if lib().drs_slab_connect(self.h, unique_id, stream) != 0:
+            raise RuntimeError("drs_slab_connect: " + lib().drs_slab_error(self.h).decode())
+
+    def run(self, d_a, d_b, iterations=-1):
+        n = lib().drs_slab_run(self.h, d_a, d_b, iterations)
+        if n < 0:
+            raise RuntimeError("drs_slab_run: " + lib().drs_slab_error(self.h).decode())
+        return n
+
+    def sync(self):
+        if lib().drs_slab_sync(self.h) != 0:
+            raise RuntimeError("drs_slab_sync failed")
+
+    @property
+    def stream(self):
+        return lib().drs_slab_stream(self.h)
+
+    @property
+    def info(self):
+        return json.loads(lib().drs_slab_info(self.h).decode())
+
+    def close(self):
+        try:
+            if getattr(self, "h", None):
+                lib().drs_slab_close(self.h)
+                self.h = None
+        except Exception:   # interpreter shutdown
+            pass
 
     __del__ = close
 

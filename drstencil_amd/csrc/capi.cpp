@@ -437,3 +437,5 @@ double drs_check_error_f32(int ndim, int L, int M, int N, int halo, const float 
 }
 
 }  // extern "C"
+
+#include "slab.hpp"

@@ -156,16 +156,39 @@ def measure_exchange_every(torch, dist, dims, H, rank, world, sweep, device, dty
         return timed(exchange) if (has_up or has_dn) else 0.0
 
     x1, x2 = exchange_us(H), exchange_us(2 * H)
-    t = torch.tensor([sweep_us, x1, x2], dtype=torch.float64, device=device)
-    dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    sweep_us, x1, x2 = float(t[0]), float(t[1]), float(t[2])
+
+    def boundary_us(every):
+        """The boundary launch(es) of an exchanging launch (both views in one dr2_ launch where the rank has two neighbours) plus the
+        event the side stream waits for -- what round 2 put in as a constant 30 us."""
+        pe = SlabPlan(dims[0], H, world, rank, every)
+        if self_neighbour and not (pe.has_up and pe.has_dn):
+            return 0.0
+        s2 = torch.zeros((pe.Lloc,) + rest, dtype=dtype, device=device)
+        d2 = torch.zeros_like(s2)
+        ev = torch.cuda.Event()
+
+        def boundary():
+            if pe.pair_view() and hasattr(sweep, "pair"):
+                sweep.pair(s2[pe.top[0]:pe.top[1]], d2[pe.top[0]:pe.top[1]], s2[pe.bot[0]:pe.bot[1]], d2[pe.bot[0]:pe.bot[1]], main.cuda_stream)
+            else:
+                for v in (pe.top, pe.bot):
+                    if v is not None:
+                        sweep(s2[v[0]:v[1]], d2[v[0]:v[1]], main.cuda_stream)
+            ev.record(main)
+        return timed(boundary) if (pe.top is not None or pe.bot is not None) else 0.0
+
     planes = min(slab_bounds(dims[0], world, r)[1] - slab_bounds(dims[0], world, r)[0] for r in range(world))
-    # time of one ping-pong pair (two launches) in each mode; ~30 us per exchanging launch for the two boundary kernels
-    # and the stream hand-overs around them (profiles/r01_rccl_probe.md)
-    pair1 = 2.0 * (30.0 + max(sweep_us, x1))
-    pair2 = sweep_us * (1.0 + 2.0 * H / planes) + 30.0 + max(sweep_us, x2)
+    b1 = boundary_us(1)
+    b2 = boundary_us(2) if planes >= 8 * H else b1
+    t = torch.tensor([sweep_us, x1, x2, b1, b2], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    sweep_us, x1, x2, b1, b2 = (float(v) for v in t)
+    # time of one ping-pong pair (two launches) in each mode: boundary launch, then the interior sweep beside the exchange
+    pair1 = 2.0 * (b1 + max(sweep_us, x1))
+    pair2 = sweep_us * (1.0 + 2.0 * H / planes) + b2 + max(sweep_us, x2)
     every = 2 if planes >= 8 * H and pair2 < pair1 else 1
     return every, {"interior_sweep_us": sweep_us, "exchange_H_planes_us": x1, "exchange_2H_planes_us": x2,
+                   "boundary_launch_us_every1": b1, "boundary_launch_us_every2": b2,
                    "pair_us_exchange_every_launch": pair1, "pair_us_one_exchange_per_pair": pair2, "chosen_every": every}
 
 
@@ -353,3 +376,51 @@ class SelfNeighbourRun(SlabRun):
                dist.P2POp(dist.isend, dst[p.send_dn[0]:p.send_dn[1]], 0), dist.P2POp(dist.irecv, dst[p.recv_up[0]:p.recv_up[1]], 0)]
         for w in dist.batch_isend_irecv(ops):
             w.wait()
+
+
+class NativeSlabRun:
+    """SlabRun's interface over the native N > 1 entry points of the C ABI (drs_slab_*, csrc/slab.hpp): the plan, the kernels,
+    the RCCL group of send/recv on a high-priority side stream and the HIP graph of one ping-pong pair all live in
+    libdrstencil_amd.so; torch only owns the two device buffers and carries the 128-byte communicator id from rank 0 to the
+    others (any transport would do).  `rehearse_world` > 0 plays a middle rank on one GPU with itself as both neighbours
+    (SelfNeighbourRun's counterpart).  Every view kernel must already be in the cache (HipSweep.prebuild built them)."""
+
+    def __init__(self, torch, dist, base_stc, opts, dims, H, step, iterations, rank, world, device, dtype, every=1, alone_opts=None,
+                 rehearse_world=0, cache_dir=None):
+        self.torch, self.dist = torch, dist
+        dims = tuple(dims)
+        pworld = rehearse_world or world
+        self.plan = SlabPlan(dims[0], H, pworld, rank, every if pworld > 1 else 1)
+        self.rest, self.H, self.step, self.iterations = dims[1:], H, step, iterations
+        self.rank, self.world, self.device, self.dtype = rank, world, device, dtype
+        self.slab = drs.Slab(list(opts) + [base_stc], world=1 if rehearse_world else world, rank=rank, every=every, alone_args=alone_opts,
+                             rehearse_world=rehearse_world, cache_dir=cache_dir)
+        p = self.plan
+        assert (self.slab.lo, self.slab.hi, self.slab.z0, self.slab.z1, self.slab.Lloc) == (p.lo, p.hi, p.z0, p.z1, p.Lloc)
+        self.A = torch.zeros((p.Lloc,) + self.rest, dtype=dtype, device=device)
+        self.B = torch.zeros((p.Lloc,) + self.rest, dtype=dtype, device=device)
+        # the communicator id: made by rank 0, carried by whatever the host has (here: the torch process group)
+        if rehearse_world or world == 1:
+            uid = drs.slab_unique_id()
+        else:
+            box = [drs.slab_unique_id() if rank == 0 else None]
+            dist.broadcast_object_list(box, src=0)
+            uid = box[0]
+        self.slab.connect(uid)
+        self.main = torch.cuda.ExternalStream(self.slab.stream, device=device)
+        self.launch_count = 0
+
+    def load_global(self, fill):
+        p = self.plan
+        self.A.copy_(self.torch.as_tensor(fill(p.lo, p.hi)).to(self.device, self.dtype))
+        self.B.zero_()
+        self.torch.cuda.synchronize()
+
+    def run(self, iterations=None):
+        n = self.slab.run(self.A.data_ptr(), self.B.data_ptr(), self.iterations if iterations is None else iterations)
+        self.launch_count += n
+        return n
+
+    def owned(self, buf):
+        p = self.plan
+        return buf[p.z0 - p.lo:p.z1 - p.lo]

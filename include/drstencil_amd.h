@@ -89,6 +89,37 @@ int drs_kernel_run(drs_kernel *k, void *d_a, void *d_b, int iterations, int gold
  * HIP events recorded on `stream`; blocks until done; *ms = elapsed milliseconds. */
 int drs_kernel_run_timed(drs_kernel *k, void *d_a, void *d_b, int iterations, int warmup, void *stream, float *ms);
 
+/* ---- N > 1: one rank of a slab-decomposed run (z slabs in 3D, y slabs in 2D), one process per GPU -----------------------------
+ * No reference counterpart: the reference is single-GPU (no cudaSetDevice / streams / NCCL anywhere; SURVEY.md section 5 sketches
+ * this layer as `ncclGroupStart; ncclSend/ncclRecv x <= 4; ncclGroupEnd` on a comm stream).  What these entry points must
+ * reproduce is the SINGLE-DOMAIN run of drs_kernel_run on the whole grid, bit for bit; drstencil_amd/multigpu.py (SlabPlan /
+ * SlabRun, the torch.distributed path) is the reference implementation they are tested against.
+ *   rank 0:      drs_slab_unique_id(id)                  -> hand the 128 bytes to every rank (MPI_Bcast, a file, a socket ...)
+ *   every rank:  s = drs_slab_open(argc, argv, ..., world, rank, every, 0, cache, &log)   plan + kernels, BEFORE any GPU call
+ *                                                          (it may start hipcc); argv = generator options + the whole grid's .stc
+ *                hipSetDevice(local_rank); drs_slab_connect(s, id, stream)    ncclCommInitRank, side stream, events
+ *                drs_slab_plan(s, p): this rank holds global planes [p[0], p[1]) = Lloc planes INCLUDING G ghost planes per
+ *                                     interior face, owns [p[2], p[3]); A and B are caller-owned device buffers of that size
+ *                n = drs_slab_run(s, d_a, d_b, iterations)                    the reference's loop (codegen.hpp:581-584) on the slab
+ *                drs_slab_sync(s); drs_slab_close(s)
+ * every = 1: each launch exchanges its output's H = step * order boundary planes with the <= 2 neighbours; every = 2: ghost
+ * planes 2H wide, one exchange per ping-pong pair.  A pair is captured once into a HIP graph per (A, B) and replayed
+ * (DRS_SLAB_GRAPH=0: eager); drs_slab_info tells ("graph": 1 captured, -1 refused -> eager).  rehearse_world > 0 plays rank
+ * `rank` of `rehearse_world` on ONE GPU with itself as both neighbours (communicator of size 1): tests and one-GPU rehearsals. */
+typedef struct drs_slab drs_slab;
+#define DRS_SLAB_ID_BYTES 128
+int drs_slab_unique_id(void *id128);
+drs_slab *drs_slab_open(int argc, const char *const *argv, int alone_argc, const char *const *alone_argv, int world, int rank, int every,
+                        int rehearse_world, const char *cache_dir, char **log);
+void drs_slab_plan(const drs_slab *s, long out[8]);   /* lo, hi, z0, z1, Lloc, G, H, every */
+int drs_slab_connect(drs_slab *s, const void *id128, void *main_stream /* hipStream_t or NULL: own stream */);
+int drs_slab_run(drs_slab *s, void *d_a, void *d_b, int iterations /* < 0: the spec's */);
+int drs_slab_sync(drs_slab *s);
+void *drs_slab_stream(drs_slab *s);
+const char *drs_slab_info(drs_slab *s);     /* JSON */
+const char *drs_slab_error(const drs_slab *s);
+void drs_slab_close(drs_slab *s);
+
 /* ---- inputs and error metric: common.hpp:9-102 (host memory) */
 void drs_fill_random_f64(double *a, size_t n, unsigned seed);   /* seed 1 == the reference's unseeded rand() */
 void drs_fill_random_f32(float *a, size_t n, unsigned seed);

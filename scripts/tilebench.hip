@@ -83,7 +83,9 @@ static void run(const char* name, const float* a, float* b, int N, int M, int L,
 
 int main()
 {
-    const int N = 1024, M = 1024, L = 1024;
+    // TILEBENCH_DIM=512: the same copies on the 512^3 grid of BASELINE C3 (round 3: what is the ceiling at 195 us launches?)
+    const int DIM = getenv("TILEBENCH_DIM") ? atoi(getenv("TILEBENCH_DIM")) : 1024;
+    const int N = DIM, M = DIM, L = DIM;
     const long pad = 64;                                  // floats: 256 bytes
     const size_t elems = (size_t)(N + pad) * M * L + 4096;
     float *a, *b;
@@ -91,7 +93,26 @@ int main()
     (void)hipMemset(a, 0, elems * 4); (void)hipMemset(b, 0, elems * 4);
     for (int padded = 0; padded < (getenv("TILEBENCH_PADDED") ? 2 : 1); padded++) {
         const long pitch = N + (padded ? pad : 0);
-        printf("---- row pitch %ld bytes%s\n", pitch * 4, padded ? " (padded by 256 bytes: NOT the reference's layout)" : " (dense: the reference's layout)");
+        printf("---- %d^3 grid, row pitch %ld bytes%s\n", DIM, pitch * 4, padded ? " (padded by 256 bytes: NOT the reference's layout)" : " (dense: the reference's layout)");
+        if (DIM != 1024) {      // tiles of up to 512 columns; stream blocks of 8-64 planes
+            run<32, 2, 3, true>("128 x 32, barrier, band map, 32-plane blocks", a, b, N, M, L, pitch, 32, 2);
+            run<32, 2, 3, true>("128 x 32, barrier, band map, 16-plane blocks", a, b, N, M, L, pitch, 16, 2);
+            run<32, 2, 3, true>("128 x 32, barrier, band map, 8-plane blocks", a, b, N, M, L, pitch, 8, 2);
+            run<32, 2, 3, true>("128 x 32, barrier, band map, 64-plane blocks", a, b, N, M, L, pitch, 64, 2);
+            run<32, 2, 3, true, 60>("128 x 32, barrier, band map, 2 wg/CU", a, b, N, M, L, pitch, 32, 2);
+            run<32, 2, 3, false>("128 x 32, no barrier, band map", a, b, N, M, L, pitch, 32, 2);
+            run<32, 2, 3, true>("128 x 32, barrier, chunk map", a, b, N, M, L, pitch, 32, 1);
+            run<32, 2, 3, true>("128 x 32, barrier, chunk map, 8-plane blocks", a, b, N, M, L, pitch, 8, 1);
+            run<32, 2, 3, true>("128 x 32, barrier, dispatch order", a, b, N, M, L, pitch, 32, 0);
+            run<32, 1, 3, true>("128 x 16, barrier, chunk map", a, b, N, M, L, pitch, 32, 1);
+            run<64, 2, 3, true>("256 x 16, barrier, chunk map", a, b, N, M, L, pitch, 32, 1);
+            run<64, 4, 3, true>("256 x 32, barrier, chunk map", a, b, N, M, L, pitch, 32, 1);
+            run<128, 4, 3, true>("512 x 16 (full rows), barrier, chunk map", a, b, N, M, L, pitch, 32, 1);
+            run<128, 4, 3, true>("512 x 16 (full rows), barrier, 4-plane blocks", a, b, N, M, L, pitch, 4, 1);
+            run<128, 4, 1, true>("512 x 16 (full rows), barrier, 4-plane, depth 1", a, b, N, M, L, pitch, 4, 1);
+            run<128, 2, 3, true>("512 x 8 (full rows), barrier, 4-plane blocks", a, b, N, M, L, pitch, 4, 1);
+            continue;
+        }
         run<32, 2, 3, true>("128 x 32, barrier, generator's band map", a, b, N, M, L, pitch, 32, 2);
         run<32, 2, 3, true>("128 x 32, barrier, band map, 8-plane blocks", a, b, N, M, L, pitch, 8, 2);
         run<32, 2, 3, true, 100>("128 x 32, barrier, band map, 1 wg/CU", a, b, N, M, L, pitch, 32, 2);

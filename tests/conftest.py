@@ -144,6 +144,15 @@ def _run_c_host(drs):
         if cc.returncode == 0:
             r = subprocess.run([exe, os.path.join(ROOT, "tests", "stc", "t3_star.stc"), "70", "45", "530", "2"], capture_output=True, text=True, timeout=300)
             text += "[host rc=%d]\n%s%s" % (r.returncode, r.stdout, r.stderr[-800:])
+        # the N > 1 entry points from plain C (tests/native/capi_slab_host.c): a middle rank of 3 on this GPU, neighbours = itself
+        exe2 = os.path.join(out, "capi_slab_host")
+        cc = subprocess.run(["gcc", "-std=gnu11", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), "-I", "/opt/rocm/include",
+                             os.path.join(ROOT, "tests", "native", "capi_slab_host.c"), "-o", exe2, "-L", libdir, "-ldrstencil_amd", "-Wl,-rpath," + libdir,
+                             "-L/opt/rocm/lib", "-lamdhip64", "-Wl,-rpath,/opt/rocm/lib"], capture_output=True, text=True, timeout=120)
+        text += "[slab gcc rc=%d]\n%s" % (cc.returncode, cc.stderr[-1500:])
+        if cc.returncode == 0:
+            r = subprocess.run([exe2, os.path.join(ROOT, "tests", "stc", "t3_star.stc"), "45", "530"], capture_output=True, text=True, timeout=300)
+            text += "[slab host rc=%d]\n%s%s" % (r.returncode, r.stdout, r.stderr[-800:])
     except Exception as e:
         text = "[exception] %r" % (e,)
     with open(os.path.join(out, "stdout.txt"), "w") as f:

@@ -235,3 +235,22 @@ def test_tuner_space_and_naming():
     for s in random.sample(space, 25):
         rc, msg, src = drs.generate(["--3d", "--dtype", "fp32"] + t.cfgToCommandLine(s).split() + [stc])
         assert rc == 0 and src, (t.cfgToString(s), msg)
+
+
+def test_native_slab_plan_equals_the_python_plan():
+    """drs_slab_open (the plan of the N > 1 entry points, C++) against multigpu.SlabPlan for every rank of worlds 2-4 and both
+    exchange modes; the view kernels are the ones build() made for the one-GPU slab tests, so nothing is compiled here."""
+    from drstencil_amd.multigpu import SlabPlan
+    stc = os.path.join(ROOT, "tests", "stc", "t3_star.stc")
+    opts = ["--3d", "--dtype", "fp32", "--step", "2", "--sn", "16"]
+    spec = drs.Spec(stc, 3, 2)
+    for every in (1, 2):
+        for rank in range(3):
+            s = drs.Slab(opts + [stc], world=3, rank=rank, every=every)
+            p = SlabPlan(spec.dims[0], spec.halo, 3, rank, every)
+            assert (s.lo, s.hi, s.z0, s.z1, s.Lloc, s.G, s.H, s.every) == (p.lo, p.hi, p.z0, p.z1, p.Lloc, p.G, p.H, p.every)
+            i = s.info
+            assert i["graph"] == 0 and (i["kernel_pair"] != "") == (p.pair_view() is not None) and (i["kernel_full"] != "") == (every == 2)
+            s.close()
+    with pytest.raises(drs.KernelBuildError):
+        drs.Slab(opts + [stc], world=1, rank=0, every=1, rehearse_world=3)      # only a middle rank can be its own two neighbours

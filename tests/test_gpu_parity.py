@@ -442,6 +442,21 @@ def test_c_host_through_the_abi():
     assert float(m.group(4)) == 0.0 and float(m.group(5)) == 1e-13 and float(m.group(6)) == 0.0    # bit-identical to the gold kernel
 
 
+def test_c_host_runs_a_slab_through_the_abi():
+    """tests/native/capi_slab_host.c: drs_slab_unique_id / open / connect / run / sync / close from plain C -- a middle rank of 3
+    with itself as both neighbours through RCCL, 12 launches, once with the captured HIP graph and once eagerly: same result."""
+    import re
+    text = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "drstencil_amd", "_kcache", "c_host", "stdout.txt")).read()
+    assert "[slab gcc rc=0]" in text and "[slab host rc=0]" in text, text[-2000:]
+    runs = re.findall(r"graph_requested (\d) info (\{.*\}) launches (\d+) lloc (\d+) ghost_width (\d+) ghosts_moved (\d)", text)
+    assert len(runs) == 2, text[-1500:]
+    for g, info, launches, lloc, gw, moved in runs:
+        i = json.loads(info)
+        assert launches == "12" and moved == "1" and gw == "4" and i["self_neighbour"] == 1 and i["every"] == 2
+        assert i["graph"] in ((1, -1) if g == "1" else (0,)), i
+    assert "eager_equals_graph 1" in text
+
+
 def test_native_library_is_the_path():
     import drstencil_amd as drs
     assert drs.lib() is not None
@@ -691,3 +706,56 @@ def test_rccl_exchange_choreography_on_one_gpu(torch_cuda, tmp_path, every):
         assert ok and detail["decomposed_vs_single_domain"]["launches"] == spec.launches
     finally:
         dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("graph", ["1", "0"], ids=["hip_graph", "eager"])
+@pytest.mark.parametrize("every", [1, 2], ids=["exchange_every_launch", "exchange_every_pair"])
+def test_native_slab_loop_equals_the_torch_one(torch_cuda, every, graph, monkeypatch):
+    """The N > 1 entry points of the C ABI (drs_slab_*: the plan in C++, RCCL called directly -- ncclCommInitRank from a
+    caller-distributed id, one ncclGroup of send/recv per exchange on a high-priority side stream --, one ping-pong pair captured
+    into a HIP graph) against multigpu.SlabRun, the torch path: a middle rank of 3 whose neighbours are itself, 12 launches,
+    both buffers bit for bit; the reference run exchanges by plain device copies (no process group involved)."""
+    import drstencil_amd as drs
+    from drstencil_amd.multigpu import HipSweep, SlabRun
+    from gpu_cases import stc as stcp
+    torch = torch_cuda
+    monkeypatch.setenv("DRS_SLAB_GRAPH", graph)
+    opts = ["--3d", "--dtype", "fp32", "--step", "2", "--sn", "16"]
+    stc = stcp("t3_star")
+    spec = oracle.Spec(stc, 3, 2)
+    L, M, N = spec.dims
+    H = spec.halo
+    dev = torch.device("cuda", 0)
+    sweep = HipSweep(stc, opts, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "drstencil_amd", "_kcache"))
+
+    class SelfCopy(SlabRun):
+        def _exchange(self, dst):
+            p = self.plan
+            dst[p.recv_dn[0]:p.recv_dn[1]].copy_(dst[p.send_up[0]:p.send_up[1]])
+            dst[p.recv_up[0]:p.recv_up[1]].copy_(dst[p.send_dn[0]:p.send_dn[1]])
+
+    A0 = torch.as_tensor(oracle.fill_random(spec.shape, np.float32))
+    ref = SelfCopy(torch, None, (L, M, N), H, 2, 24, 1, 3, sweep, dev, torch.float32, every=every)
+    ref.load_global(lambda lo, hi: A0[lo:hi])
+    assert ref.run() == 12
+    torch.cuda.synchronize()
+    slab = drs.Slab(opts + [stc], world=1, rank=1, every=every, rehearse_world=3)
+    p = ref.plan
+    assert (slab.lo, slab.hi, slab.z0, slab.z1, slab.Lloc, slab.G, slab.H, slab.every) == (p.lo, p.hi, p.z0, p.z1, p.Lloc, p.G, p.H, p.every)
+    slab.connect(drs.slab_unique_id())
+    A = A0[slab.lo:slab.hi].to(dev).contiguous()
+    B = torch.zeros_like(A)
+    torch.cuda.synchronize()                       # the slab runs on its own stream
+    assert slab.run(A.data_ptr(), B.data_ptr(), 24) == 12
+    slab.sync()
+    info = slab.info
+    assert info["self_neighbour"] == 1 and info["graph"] == (1 if graph == "1" else 0) or info["graph"] == -1, info
+    assert torch.equal(A, ref.A) and torch.equal(B, ref.B), info
+    assert bool((A[:slab.G] != A0[slab.lo:slab.lo + slab.G].to(dev)).any()), "ghost planes were never exchanged"
+    # a second run on the same buffers replays the captured pair
+    assert slab.run(A.data_ptr(), B.data_ptr(), 4) == 2
+    slab.sync()
+    ref.run(iterations=4)
+    torch.cuda.synchronize()
+    assert torch.equal(A, ref.A) and torch.equal(B, ref.B)
+    slab.close()
