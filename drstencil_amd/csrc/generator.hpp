@@ -113,6 +113,8 @@ MI355X options:
 --stage <reg|dma>       How an arriving plane reaches LDS in streaming kernels: reg (default) = global loads into VGPRs
                         (software prefetch) + LDS writes; dma = LDS-DMA (global_load_lds_dwordx4) straight into the plane's
                         LDS slot, one plane ahead, no prefetch registers (16-byte vectors, block y merging, one stage).
+--loader-waves <n>      With --stage dma: n extra wavefronts per workgroup only request planes by LDS-DMA, --prefetch-depth planes
+                        ahead into a ring of LDS slots, counting their own vmcnt; the bx*by consumer lanes never issue a load.
 --defer-stores <0|1>    Hold a completed output plane in registers and store it one plane later, right after the next
                         plane's loads were issued (its write latency runs under that plane's work).
 --drain <0|1|2>         s_waitcnt vmcnt(0) before every plane's prefetch loads (1) or before its LDS staging (2).
@@ -181,6 +183,7 @@ inline GenResult generate(const std::vector<std::string> &args /* argv[1..] */) 
         else if (a == "--order") { if (!str_opt(o.order)) break; }
         else if (a == "--pack") { if (!int_opt(o.pack, nullptr)) break; }
         else if (a == "--row-fence") { if (!int_opt(o.row_fence, nullptr)) break; }
+        else if (a == "--loader-waves") { if (!int_opt(o.loader_waves, nullptr)) break; }
         else if (a == "--rot-mod") { if (!int_opt(o.rot_mod, nullptr)) break; }
         else if (a == "--pin") { if (!int_opt(o.pin, nullptr)) break; }
         else if (a == "--exact-y") { if (!int_opt(o.exact_y, nullptr)) break; }

@@ -112,6 +112,11 @@ struct GenOptions {
     std::string stage = "reg";   // how an arriving plane gets into LDS: reg = global loads into VGPRs (software prefetch), then ds_write;
                                  // dma = LDS-DMA (global_load_lds_dwordx4): the plane lands in its LDS slot without touching VGPRs, one plane
                                  // ahead of the one being summed (look-ahead costs an LDS slot instead of prefetch register sets)
+    int loader_waves = 0;        // --stage dma --loader-waves n (round 3, wave specialisation): n extra wavefronts per workgroup do nothing but request
+                                 // planes by LDS-DMA into a ring of prefetch-depth + 1 LDS slots and count their own vmcnt; the bx*by "consumer"
+                                 // lanes never issue a load: barrier, read the landed plane from LDS, sum, store.  Loads and stores sit in
+                                 // different wavefronts' queues, no consumer drains loads, no prefetch registers (a stencil-free copy of the
+                                 // headline's tile shape: 1.436 -> 1.376 ms with 8-plane blocks, profiles/r03_exp_wave_specialised_copy.log)
     std::vector<std::string> cc_opts;   // --cc-opt <flag> (repeatable): extra hipcc flags for this kernel (e.g. -fno-slp-vectorize); part of the
                                  // kernel's identity: printed in the banner's build line and applied by drs_kernel_build
     std::string store_mask = "branch";  // branch: plain global stores under per-lane guards (default: measured faster);
@@ -180,6 +185,7 @@ struct KernelPlan {
     int UN = 1;              // unroll of the streaming loop
     bool prefetch = false;
     int PD = 1;              // prefetch depth (planes in flight)
+    int ws = 0;              // loader wavefronts (--loader-waves): planes are requested by them, DEPTH = PD planes ahead, into NSLOT = PD + 1 slots
     bool dma = false;        // --stage dma: planes are staged by LDS-DMA into a per-lane-dense LDS image (emit_hip.hpp)
     // temporal blocking and the tolerance (planner.hpp: temporal_drift): which arithmetic the kernel computes
     bool reassociated = false;   // true: on-chip stages (equal to the reference's fused arithmetic up to rounding); false: gold order, bit-exact

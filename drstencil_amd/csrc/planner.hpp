@@ -253,6 +253,7 @@ inline KernelPlan make_plan(const Stencil &st, const GenOptions &o_in, const std
     p.NBS = p.has_s ? std::max(1, ceil_div(p.DS - 2 * H, p.SN)) : 1;
     if (p.DX - 2 * H < 1 || (p.has_y && p.DY - 2 * H < 1) || (p.has_s && p.DS - 2 * H < 1)) { p.error = "grid has no interior"; return p; }
 
+    if (o.loader_waves > 0 && o.stage != "dma") { p.error = "--loader-waves goes with --stage dma"; return p; }
     if (o.stage == "dma") {
         // LDS-DMA writes 64 lanes x 16 bytes of one wavefront instruction to consecutive LDS addresses: the LDS image is
         // dense per (row, vector, lane) and the halo pieces dense per loader task (emit_hip.hpp); what that needs:
@@ -265,6 +266,12 @@ inline KernelPlan make_plan(const Stencil &st, const GenOptions &o_in, const std
         if (!p.exact_x) { p.error = "--stage dma needs --exact-x 1"; return p; }
         p.dma = true;
         p.prefetch = false;      // the look-ahead is the DMA itself
+        if (o.loader_waves > 0) {
+            if (p.NT % 64 != 0) { p.error = "--loader-waves needs whole consumer wavefronts (bx * by a multiple of 64)"; return p; }
+            if (p.NT + 64 * o.loader_waves > 1024) { p.error = "--loader-waves: more than 1024 lanes per workgroup"; return p; }
+            if (o.schedule != "scatter" || o.defer_stores) { p.error = "--loader-waves needs --schedule scatter without --defer-stores"; return p; }
+            p.ws = o.loader_waves;
+        }
     }
     p.SROW = p.PADL + p.TX + p.PADR + o.lds_pad;
     p.SROWS = p.has_y ? p.TY + p.hym + p.hyp : 1;

@@ -60,6 +60,95 @@ __global__ __launch_bounds__(512) void tile_copy(const float* __restrict__ in, f
     }
 }
 
+
+// Round 3: WAVE-SPECIALISED copy of the same tile shape.  NLW "loader" wavefronts per workgroup do nothing but
+// request planes by LDS-DMA (global_load_lds_dwordx4: 64 lanes x 16 B land at consecutive LDS addresses) into a ring of NSLOT plane
+// slots, DEPTH planes ahead, and count their own vmcnt; the 8 "consumer" wavefronts (the 512 lanes of tile_copy) never issue a load:
+// barrier, read their points of the landed plane from LDS, store them.  Reads and writes sit in different wavefronts' queues, no
+// consumer drains loads, no prefetch registers.  One barrier per plane as in the stencil kernels.
+template <int LX, int RY, int DEPTH, int NLW>
+__global__ __launch_bounds__(512 + 64 * NLW) void tile_copy_ws(const float* __restrict__ in, float* __restrict__ out, int N, int M, int L, long pitch, long plane, int sn, int band)
+{
+    constexpr int LY = 512 / LX, TW = LX * 4, TH = LY * RY, NSLOT = DEPTH + 1;
+    constexpr int ROWB = TW * 4;                         // bytes of a tile row
+    constexpr int PLANE_V4 = TW * TH / 4;                // 16-byte pieces of a tile plane
+    constexpr int PIECES = PLANE_V4 / 64;                // wavefront instructions per plane
+    __shared__ __attribute__((aligned(16))) float ring[NSLOT * TW * TH];
+    const int tiles_x = N / TW, tiles_y = M / TH, tiles = tiles_x * tiles_y;
+    int wg = blockIdx.x, zb, t;
+    if (band == 2) { const int xcd = wg % 8, slot = wg / 8, per = tiles / 8; t = xcd * per + slot % per; zb = slot / per; }
+    else { if (band) { const int per = gridDim.x / 8; wg = (wg % 8) * per + wg / 8; } zb = wg / tiles; t = wg % tiles; }
+    const int tx = t % tiles_x, ty = t / tiles_x;
+    const int k0 = zb * sn, k1 = min(k0 + sn, L);
+    const long tile_org = (long)(ty * TH) * pitch + (long)tx * TW;
+    const int tid = threadIdx.x;
+    if (tid >= 512) {
+        // ---- loader wavefront lw of NLW: pieces lw, lw + NLW, ... of every plane
+        const int lw = (tid - 512) / 64, lane = tid & 63;
+        auto request = [&](int k) {
+            const float* src = in + (long)k * plane + tile_org;
+            float* dst = ring + (size_t)((k - k0) % NSLOT) * TW * TH;
+#pragma unroll
+            for (int pc = lw; pc < PIECES; pc += NLW) {
+                const int v = pc * 64 + lane;            // 16-byte piece of the tile plane, row-major
+                const int row = v / (TW / 4), col4 = v % (TW / 4);
+                __builtin_amdgcn_global_load_lds(src + (long)row * pitch + col4 * 4, dst + pc * 256, 16, 0, 0);
+            }
+        };
+        for (int d = 0; d < DEPTH; d++) if (k0 + d < k1) request(k0 + d);
+        constexpr int PER = (PIECES + NLW - 1) / NLW;    // my instructions per plane (PIECES divisible by NLW in the shapes used)
+        for (int k = k0; k < k1; k++) {
+            // plane k has landed when at most (planes still in flight behind it) x PER of my requests are outstanding
+            const int behind = min(DEPTH - 1, k1 - 1 - k);
+            if (behind >= 3) __builtin_amdgcn_s_waitcnt(0x0f70 | ((3 * PER) & 0xf) | ((((3 * PER) >> 4) & 3) << 14));
+            else if (behind == 2) __builtin_amdgcn_s_waitcnt(0x0f70 | ((2 * PER) & 0xf) | ((((2 * PER) >> 4) & 3) << 14));
+            else if (behind == 1) __builtin_amdgcn_s_waitcnt(0x0f70 | ((1 * PER) & 0xf) | ((((1 * PER) >> 4) & 3) << 14));
+            else __builtin_amdgcn_s_waitcnt(0x0f70);
+            __syncthreads();                             // plane k is in LDS for everyone; the consumers are done with plane k - 1
+            if (k + DEPTH < k1) request(k + DEPTH);      // into the slot plane k - 1 occupied
+        }
+        return;
+    }
+    // ---- consumer wavefronts: the 512 lanes of tile_copy
+    const int lx = tid % LX, ly = tid / LX;
+    float* pout = out + (long)k0 * plane + tile_org + (long)(ly * RY) * pitch + lx * 4;
+    for (int k = k0; k < k1; k++) {
+        __syncthreads();
+        const float* slot = ring + (size_t)((k - k0) % NSLOT) * TW * TH;
+#pragma unroll
+        for (int r = 0; r < RY; r++) {
+            const v4 x = *(const v4*)(slot + (ly * RY + r) * TW + lx * 4);
+            __builtin_nontemporal_store(x, (v4*)(pout + (long)(k - k0) * plane + (long)r * pitch));
+        }
+    }
+}
+
+template <int LX, int RY, int DEPTH, int NLW>
+static void run_ws(const char* name, const float* a, float* b, int N, int M, int L, long pitch, int sn, int band)
+{
+    constexpr int TW = LX * 4, TH = (512 / LX) * RY;
+    const long plane = pitch * M;
+    const int grid = (N / TW) * (M / TH) * ((L + sn - 1) / sn);
+    hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+    for (int w = 0; w < 3; w++) tile_copy_ws<LX, RY, DEPTH, NLW><<<grid, 512 + 64 * NLW>>>(a, b, N, M, L, pitch, plane, sn, band);
+    float best = 1e9f, sum = 0;
+    for (int r = 0; r < 7; r++) {
+        (void)hipEventRecord(e0, 0);
+        for (int i = 0; i < 5; i++) tile_copy_ws<LX, RY, DEPTH, NLW><<<grid, 512 + 64 * NLW>>>(a, b, N, M, L, pitch, plane, sn, band);
+        (void)hipEventRecord(e1, 0); (void)hipEventSynchronize(e1);
+        float ms; (void)hipEventElapsedTime(&ms, e0, e1); ms /= 5; sum += ms; if (ms < best) best = ms;
+    }
+    const double bytes = 2.0 * 4.0 * N * (double)M * L;
+    printf("%-52s sn %4d  tile %4d x %3d  %d loader waves, %d planes ahead: %.3f ms (best %.3f)  %.0f GB/s  (%.1f %% of 8 TB/s)\n", name, sn, TW, TH, NLW, DEPTH, sum / 7, best,
+           bytes / (sum / 7 * 1e-3) / 1e9, bytes / (sum / 7 * 1e-3) / 8e12 * 100);
+    if (hipGetLastError() != hipSuccess) printf("  launch error\n");
+    // the copy must be a copy: compare a few words of the last plane
+    float ha[4], hb[4];
+    const size_t probe = (size_t)(L - 1) * plane + (size_t)(M - 1) * pitch + N - 4;
+    (void)hipMemcpy(ha, a + probe, 16, hipMemcpyDeviceToHost); (void)hipMemcpy(hb, b + probe, 16, hipMemcpyDeviceToHost);
+    if (ha[0] != hb[0] || ha[3] != hb[3]) printf("  COPY MISMATCH\n");
+}
+
 template <int LX, int RY, int DEPTH, bool SYNC = false, int LDSKB = 0, bool STORE_FIRST = false>
 static void run(const char* name, const float* a, float* b, int N, int M, int L, long pitch, int sn, int band)
 {
@@ -90,10 +179,26 @@ int main()
     const size_t elems = (size_t)(N + pad) * M * L + 4096;
     float *a, *b;
     if (hipMalloc(&a, elems * 4) != hipSuccess || hipMalloc(&b, elems * 4) != hipSuccess) { printf("hipMalloc failed\n"); return 1; }
-    (void)hipMemset(a, 0, elems * 4); (void)hipMemset(b, 0, elems * 4);
+    (void)hipMemset(a, 0x3c, elems * 4); (void)hipMemset(b, 0, elems * 4);
     for (int padded = 0; padded < (getenv("TILEBENCH_PADDED") ? 2 : 1); padded++) {
         const long pitch = N + (padded ? pad : 0);
         printf("---- %d^3 grid, row pitch %ld bytes%s\n", DIM, pitch * 4, padded ? " (padded by 256 bytes: NOT the reference's layout)" : " (dense: the reference's layout)");
+        if (getenv("TILEBENCH_WS")) {     // round 3: the wave-specialised copy against the plain one of the same shape, interleaved
+            for (int rep = 0; rep < 2; rep++) {
+                run<32, 2, 3, true>("plain: 128 x 32, barrier, band map", a, b, N, M, L, pitch, 32, 2);
+                run<32, 2, 3, true>("plain: 128 x 32, barrier, band map, 8-plane blocks", a, b, N, M, L, pitch, 8, 2);
+                run_ws<32, 2, 3, 2>("wave-specialised: 128 x 32, band map", a, b, N, M, L, pitch, 32, 2);
+                run_ws<32, 2, 3, 1>("wave-specialised: 128 x 32, band map", a, b, N, M, L, pitch, 32, 2);
+                run_ws<32, 2, 3, 4>("wave-specialised: 128 x 32, band map", a, b, N, M, L, pitch, 32, 2);
+                run_ws<32, 2, 2, 2>("wave-specialised: 128 x 32, band map", a, b, N, M, L, pitch, 32, 2);
+                run_ws<32, 2, 3, 2>("wave-specialised: 128 x 32, band map, 8-plane blocks", a, b, N, M, L, pitch, 8, 2);
+                run_ws<32, 2, 3, 2>("wave-specialised: 128 x 32, chunk map", a, b, N, M, L, pitch, 32, 1);
+                run<64, 2, 3, true>("plain: 256 x 16, barrier, band map", a, b, N, M, L, pitch, 32, 2);
+                run_ws<64, 2, 3, 2>("wave-specialised: 256 x 16, band map", a, b, N, M, L, pitch, 32, 2);
+                run_ws<64, 4, 3, 2>("wave-specialised: 256 x 32, band map", a, b, N, M, L, pitch, 32, 2);
+            }
+            continue;
+        }
         if (DIM != 1024) {      // tiles of up to 512 columns; stream blocks of 8-64 planes
             run<32, 2, 3, true>("128 x 32, barrier, band map, 32-plane blocks", a, b, N, M, L, pitch, 32, 2);
             run<32, 2, 3, true>("128 x 32, barrier, band map, 16-plane blocks", a, b, N, M, L, pitch, 16, 2);

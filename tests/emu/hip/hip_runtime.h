@@ -48,10 +48,17 @@ inline ucontext_t sched_ctx;
 inline Fiber *cur = nullptr;
 inline std::function<void()> *body = nullptr;
 inline int xchg[1024];
+// a counting barrier (round 3: wave-specialised kernels run loader wavefronts on another code path than the consumers, so "one yield
+// per barrier" no longer pairs the right program points -- the consumers' DPP emulation yields too): a fiber leaves __syncthreads()
+// only when every live fiber of the workgroup has arrived; fibers that have returned are not waited for (s_barrier semantics)
+inline unsigned bar_arrived = 0, bar_gen = 0, live = 0;
+inline void release_if_complete() { if (live > 0 && bar_arrived == live) { bar_arrived = 0; bar_gen++; } }
 
 inline void trampoline() {
     (*body)();
     cur->done = true;
+    live--;
+    release_if_complete();
     swapcontext(&cur->ctx, &sched_ctx);
 }
 inline void yield() { swapcontext(&cur->ctx, &sched_ctx); }
@@ -62,6 +69,7 @@ inline void run_block(dim3 block, std::function<void()> fn) {
     fibers.assign(nt, Fiber());
     while (stack_pool.size() < nt) stack_pool.push_back((char *)malloc(kStack));
     body = &fn;
+    bar_arrived = 0; bar_gen = 0; live = nt;
     for (unsigned t = 0; t < nt; t++) {
         Fiber &f = fibers[t];
         f.stack = stack_pool[t];
@@ -101,7 +109,12 @@ inline void launch(dim3 grid, dim3 block, std::function<void()> fn) {
 }
 }  // namespace emu
 
-inline void __syncthreads() { emu::yield(); }
+inline void __syncthreads() {
+    const unsigned gen = emu::bar_gen;
+    emu::bar_arrived++;
+    emu::release_if_complete();
+    do emu::yield(); while (emu::bar_gen == gen);
+}
 
 #define hipLaunchKernelGGL(kern, grid, block, shmem, stream, ...) \
     emu::launch((grid), (block), [&]() { kern(__VA_ARGS__); })

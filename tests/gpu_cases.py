@@ -101,6 +101,14 @@ _add("2d_ahead_fp32_stream_rows", 2, "t2_ahead", "--dtype", "fp32", "--streaming
 _add("3d7_fp32_s2_pinned_taps", 3, "t3_star", "--dtype", "fp32", "--step", "2", "--sn", "16", "--prefetch", "--prefetch-depth", "3", "--pin", "1", "--cc-opt", "-fno-slp-vectorize")
 _add("3d7_fp64_s3_pinned_taps", 3, "t3_star", "--dtype", "fp64", "--step", "3", "--sn", "16", "--pin", "1")
 
+# round 3: wave specialisation (--stage dma --loader-waves n: n extra wavefronts request the planes by LDS-DMA into a ring of LDS slots and
+# count their own vmcnt; the consumer lanes never load)
+_add("3d7_fp32_s2_loader_waves2", 3, "smoke3", "--dtype", "fp32", "--step", "2", "--sn", "16", "--stage", "dma", "--loader-waves", "2", "--prefetch-depth", "3", "--pin", "1")
+_add("3d7_fp64_s2_loader_waves3_depth2", 3, "t3_star", "--dtype", "fp64", "--step", "2", "--sn", "9", "--stage", "dma", "--loader-waves", "3", "--prefetch-depth", "2", "--bx", "32", "--by", "8", "--block-merge-y", "2")
+_add("3dodd_fp32_loader_waves1_depth1_lds", 3, "t3_odd", "--dtype", "fp32", "--stage", "dma", "--loader-waves", "1", "--prefetch-depth", "1", "--xrim", "lds", "--sn", "7")
+_add("3d7_fp32_s3_loader_waves2", 3, "smoke3", "--dtype", "fp32", "--step", "3", "--sn", "16", "--stage", "dma", "--loader-waves", "2", "--prefetch-depth", "2", "--pin", "1", "--bx", "32", "--by", "16", "--block-merge-y", "2")
+_add("2d25_fp32_stream_loader_waves2", 2, "t2_box25", "--dtype", "fp32", "--streaming", "--stage", "dma", "--loader-waves", "2")
+
 # --stage dma (round 2): planes staged by LDS-DMA (global_load_lds_dwordx4) into the per-lane-dense LDS image, tile-edge lanes re-reading
 # from the halo regions; every schedule, both x-rim paths, box corners, wide halos (hx > points per lane), ragged grids
 _add("3d7_fp64_dma", 3, "t3_star", "--dtype", "fp64", "--stage", "dma", "--sn", "8")

@@ -69,6 +69,13 @@ VARIANTS = [
     ("3d_s2_rows_lds_rim", 3, "STAR3", (17, 21, 300), ["--3d", "--dtype", "fp32", "--sn", "6", "--step", "2", "--xrim", "lds", "--order", "rows"]),
     ("3d_s2_rows_two_points_per_lane", 3, "STAR3", (17, 21, 300), ["--3d", "--dtype", "fp32", "--sn", "6", "--step", "2", "--order", "rows", "--bx", "16", "--block-merge-x", "2", "--by", "4", "--block-merge-y", "3"]),
     ("3d_s2_taps_pinned", 3, "STAR3", (17, 21, 300), ["--3d", "--dtype", "fp32", "--sn", "6", "--step", "2", "--prefetch", "--pin", "1"]),
+    # round 3: wave specialisation -- loader wavefronts request planes by LDS-DMA into a ring, consumers never load (the fibers' barrier counts
+    # arrivals since this round: loaders and consumers run different code between barriers)
+    ("3d_s2_loader_waves2_depth3", 3, "STAR3", (17, 21, 300), ["--3d", "--dtype", "fp32", "--sn", "6", "--step", "2", "--stage", "dma", "--loader-waves", "2", "--prefetch-depth", "3"]),
+    ("3d_s1_loader_waves1_depth1", 3, "STAR3", (12, 17, 264), ["--3d", "--dtype", "fp32", "--sn", "8", "--stage", "dma", "--loader-waves", "1", "--prefetch-depth", "1"]),
+    ("3d_s2_fp64_loader_waves3", 3, "STAR3", (15, 19, 140), ["--3d", "--dtype", "fp64", "--sn", "5", "--step", "2", "--stage", "dma", "--loader-waves", "3", "--prefetch-depth", "2", "--bx", "32", "--by", "8", "--block-merge-y", "2"]),
+    ("2d25_stream_loader_waves2", 2, "BOX25", (1, 61, 268), ["--dtype", "fp32", "--streaming", "--sn", "9", "--stage", "dma", "--loader-waves", "2"]),
+    ("3d_cross_loader_waves2_lds", 3, "CROSS3", (14, 19, 136), ["--3d", "--dtype", "fp32", "--dist", "2", "--schedule", "scatter", "--stage", "dma", "--loader-waves", "2", "--xrim", "lds"]),
     ("2d_refdefaults", 2, "BOX9", (1, 41, 70), ["--dtype", "fp64", "--ref-defaults"]),
     ("3d_step2_prefetch_depth2", 3, "STAR3", (23, 21, 300), ["--3d", "--dtype", "fp32", "--sn", "7", "--step", "2", "--prefetch", "--prefetch-depth", "2"]),
     ("3d_step1_prefetch_depth3", 3, "STAR3", (19, 23, 270), ["--3d", "--dtype", "fp64", "--sn", "5", "--prefetch", "--prefetch-depth", "3", "--xrim", "lds"]),
