@@ -135,6 +135,11 @@ FUSED3 = {
     # C2 (2d5pt_star 8192^2 fp32, one-shot LDS tiles): the fused 25-point (step 3) and 41-point (step 4) stencils, 2166 / 2732 GStencil/s bit-exact
     "c2": [["--dtype", "fp32", "--step", "4", "--bx", "128", "--by", "4", "--block-merge-x", "4", "--block-merge-y", "4", "--xcd-remap", "0", "--order", "rows", "--pack", "0"],
            ["--dtype", "fp32", "--step", "3", "--bx", "128", "--by", "4", "--block-merge-x", "4", "--block-merge-y", "4", "--xcd-remap", "0", "--order", "rows", "--pack", "0"]],
+    # the reference's precision: fused --step 3 in fp64, 899 / 835 GStencil/s against 702 / 704 for the step-2 kernels (profiles/r03_exp_r3f.log)
+    "c4f64": [["--3d", "--dtype", "fp64", "--step", "3", "--prefetch", "--prefetch-depth", "1", "--order", "rows", "--bx", "64", "--by", "8", "--block-merge-x", "2", "--block-merge-y", "2", "--sn", "64", "--xcd-remap", "2"],
+              ["--3d", "--dtype", "fp64", "--step", "3", "--prefetch", "--prefetch-depth", "1", "--order", "rows", "--bx", "128", "--by", "4", "--block-merge-x", "2", "--block-merge-y", "2", "--sn", "64", "--xcd-remap", "2"]],
+    "c3f64": [["--3d", "--dtype", "fp64", "--step", "3", "--prefetch", "--prefetch-depth", "1", "--order", "rows", "--bx", "64", "--by", "8", "--block-merge-x", "2", "--block-merge-y", "2", "--sn", "64", "--xcd-remap", "1"],
+              ["--3d", "--dtype", "fp64", "--step", "3", "--prefetch", "--prefetch-depth", "1", "--order", "rows", "--bx", "128", "--by", "4", "--block-merge-x", "2", "--block-merge-y", "2", "--sn", "32", "--xcd-remap", "2"]],
     "c3": [_S3 + ["--bx", "64", "--by", "8", "--block-merge-y", "2", "--sn", "64", "--xcd-remap", "1"],
            _S3 + ["--bx", "32", "--by", "16", "--block-merge-y", "2", "--sn", "32", "--xcd-remap", "2"],
            _S3 + ["--bx", "16", "--by", "16", "--block-merge-y", "2", "--sn", "64", "--xcd-remap", "2"]],

@@ -186,7 +186,13 @@ class Kernel:
     """A generated kernel: drstencil options -> HIP source -> hipcc (gfx950) -> loaded.
 
     `args` are exactly the `drstencil` command-line arguments (ending with the .stc path).
-    Buffers are raw device pointers (ints), e.g. torch.Tensor.data_ptr()."""
+    Buffers are raw device pointers (ints), e.g. torch.Tensor.data_ptr().
+
+    Lifetime of the plugin (the compiled .so): a Kernel that is garbage-collected or close()d releases its handle only
+    (drs_kernel_close) -- the shared object STAYS MAPPED and its code object stays registered with the HIP runtime for the life of
+    the process, so a long-lived process that builds a few kernels never pays for reloading, and launches still in flight are safe.
+    unload() (drs_kernel_unload) synchronises the device and dlcloses the plugin: that is what sweeps over thousands of kernels
+    (the tuner, the fuzzers) call after each measurement.  Nothing is unmapped implicitly."""
 
     def __init__(self, args, cache_dir=None):
         n, arr = _argv(args)
@@ -257,6 +263,7 @@ class Kernel:
         return 2 * (4 if i["dtype"] == "fp32" else 8) * pts
 
     def close(self):
+        """Release the handle; the plugin stays mapped (see the class docstring)."""
         try:
             if getattr(self, "h", None):
                 lib().drs_kernel_close(self.h)
