@@ -12,6 +12,7 @@ import oracle
 from drstencil_amd.tuner import tuning as t
 from concurrent.futures import ProcessPoolExecutor
 
+ROUND3 = os.environ.get("FUZZ_ROUND3", "1") != "0"      # 0: the round-2 sweep (same seeds, same configurations as then)
 STCS = [(3, "t3_star", 1), (3, "t3_cross", 1), (3, "t3_odd", 1), (2, "t2_star", 1), (2, "t2_box25", 2), (2, "t2_box9", 1), (2, "t2_star9", 2)]
 
 def build(job):
@@ -19,6 +20,32 @@ def build(job):
         drs.Kernel(job[3]); return None
     except Exception as e:
         return "%s: %s" % (" ".join(job[3]), " ".join(str(e).split())[:260])
+
+def round3_knobs(rnd, cl):
+    """Round 3's emission knobs, drawn AFTER everything else (the earlier draws of a seed stay what they were): --order rows with
+    --pack / --row-fence / --rot-mod, --pin on the taps order, and loader wavefronts behind --stage dma."""
+    reuse = "--schedule" not in cl                  # cfgToCommandLine spells scatter out; an explicit --dist alone selects the reuse schedule
+    dma = "--stage" in cl
+    cyc = "--cyclic-merge-y" in cl and cl[cl.index("--cyclic-merge-y") + 1] != "1"
+    r = rnd.random()
+    if r < 0.4 and not reuse and not dma and not cyc:
+        cl += ["--order", "rows"]
+        if rnd.random() < 0.5:
+            cl += ["--pack", "0"]
+        if rnd.random() < 0.25:
+            cl += ["--row-fence", "-1"]
+        if rnd.random() < 0.3:
+            cl += ["--pin", "0"]
+    elif r < 0.6:
+        cl += ["--pin", "1"]
+    if rnd.random() < 0.3 and not reuse:
+        cl += ["--rot-mod", str(rnd.choice([4, 6, 8, 9, 12]))]
+    if dma and not reuse and "--defer-stores" not in cl and rnd.random() < 0.6:
+        cl += ["--loader-waves", str(rnd.choice([1, 2, 3]))]
+        if "--prefetch-depth" not in cl:
+            cl += ["--prefetch-depth", str(rnd.choice([1, 2, 3, 4]))]
+    return cl
+
 
 def make_jobs(n, seed):
     """n random configurations (tuner space x test stencils x dtypes): (ndim, stc, dtype, drstencil args, step)."""
@@ -51,6 +78,8 @@ def make_jobs(n, seed):
                     cl += ["--stage", "dma"]
                 if random.random() < 0.3:
                     cl += ["--defer-stores", "1"]
+                if ROUND3:
+                    round3_knobs(random, cl)
                 args = (["--3d"] if ndim == 3 else []) + ["--dtype", dtype] + cl + [stc]
                 jobs.append((ndim, stc, dtype, args, v[0]))
     return jobs

@@ -111,6 +111,8 @@ def make_jobs(nshapes, per, seed):
                     cl += ["--stage", "dma"]
                 if rnd.random() < 0.2:
                     cl += ["--defer-stores", "1"]
+                if fp.ROUND3:
+                    fp.round3_knobs(rnd, cl)
                 args = (["--3d"] if ndim == 3 else []) + ["--dtype", dtype] + cl + [stc]
                 if not t.registerFilter(args):   # the tuner's spill model: do not compile what would be refused for scratch
                     dropped[0] += 1

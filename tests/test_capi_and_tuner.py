@@ -254,3 +254,63 @@ def test_native_slab_plan_equals_the_python_plan():
             s.close()
     with pytest.raises(drs.KernelBuildError):
         drs.Slab(opts + [stc], world=1, rank=0, every=1, rehearse_world=3)      # only a middle rank can be its own two neighbours
+
+
+def test_round3_emission_knobs_and_tuner_dimension(tmp_path):
+    """Round 3: the emitter bounds live ranges itself.  The knobs are validated by the generator, show up in the kernel info, never
+    change the gold kernel, and form the tuner's 17th dimension (`emit`: taps | pin | rows | rowspk) with its own name fragments."""
+    import json
+    from drstencil_amd.tuner import tuning as t
+    stc = os.path.join(ROOT, "tests", "stc", "smoke3.stc")          # 40 x 36 x 256: 16-byte vectors
+
+    def info(args):
+        rc, msg, src = drs.generate(args + [stc])
+        assert rc == 0 and src, msg
+        return json.loads(re.search(r'return "(\{.*\})";', src).group(1).replace('\\"', '"')), src
+
+    base = ["--3d", "--dtype", "fp32", "--step", "3", "--prefetch", "--prefetch-depth", "1", "--bx", "32", "--by", "8", "--block-merge-y", "2"]
+    i0, s0 = info(base)
+    assert (i0["order"], i0["packed"], i0["pinned"], i0["unroll"]) == ("taps", 0, 0, 14) and "DRS_PIN" not in s0
+    i1, s1 = info(base + ["--order", "rows"])
+    assert (i1["order"], i1["packed"], i1["pinned"]) == ("rows", 1, 1)
+    assert i1["unroll"] == 8, "Range 7 rotates through 8 sets with --order rows: 8 plane bodies instead of 14"
+    assert "DRS_ROW_FENCE();" in s1 and "DRS_PIN(cq0_" in s1 and "__builtin_elementwise_fma((vec2_t)" in s1 and "typedef real_t vec2_t" in s1
+    assert "bound_ctrl" not in s1 and "0x138, 0xf, 0xf, true)" in s1            # DPP moves without an `old` operand
+    i2, s2 = info(base + ["--order", "rows", "--pack", "0", "--rot-mod", "-1"])
+    assert (i2["packed"], i2["unroll"]) == (0, 14) and "vec2_t" not in s2
+    i3, s3 = info(base + ["--pin", "1", "--rot-mod", "9"])
+    assert (i3["order"], i3["pinned"], i3["unroll"]) == ("taps", 1, 18) and "DRS_PIN(c0_" in s3
+    # the gold kernel and the arithmetic never depend on the emission
+    gold = lambda src: src[src.index("// naive reference kernel"):src.index("// ---- launch entry points")]
+    assert gold(s0) == gold(s1) == gold(s2) == gold(s3)
+    # fp64 is never packed; a 2D tile kernel takes the rows order too
+    assert info(["--3d", "--dtype", "fp64", "--step", "2", "--order", "rows"])[0]["packed"] == 0
+    assert info(["--3d", "--dtype", "fp64", "--step", "2", "--order", "rows"])[0]["pinned"] == 1
+    # what the rows order cannot be combined with is refused like any invalid configuration (exit 255, the reference's message)
+    for bad in (["--order", "rows", "--dist", "2"], ["--order", "rows", "--schedule", "window"], ["--order", "rows", "--stage", "dma"],
+                ["--order", "rows", "--cyclic-merge-y", "2"], ["--order", "columns"], ["--loader-waves", "2"],
+                ["--stage", "dma", "--loader-waves", "9"], ["--stage", "dma", "--loader-waves", "2", "--schedule", "window"]):
+        rc, msg, src = drs.generate(["--3d", "--dtype", "fp32", "--step", "2"] + bad + [stc])
+        assert rc == 255 and not src and ("Invalid configuration!" in msg or "Illegal input." in msg), (bad, rc, msg)
+    # loader wavefronts: 2 extra wavefronts, a ring of prefetch-depth + 1 slots, every plane request unconditional
+    i4, s4 = info(["--3d", "--dtype", "fp32", "--step", "2", "--stage", "dma", "--loader-waves", "2", "--prefetch-depth", "3", "--bx", "32", "--by", "8", "--block-merge-y", "2"])
+    assert i4["threads"] == 256 and i4["lds_slots"] == 4 and "#define DRS_NTL 384" in s4 and "__launch_bounds__(384)" in s4
+    assert "if (tid >= DRS_NT)" in s4 and "DRS_VMWAIT(" in s4 and "dim3(DRS_NTL)" in s4
+    # the tuner's emission dimension
+    t.order, t.ndim, t.elem_bytes = 1, 3, 4
+    v = (3, 3, (64, 8), 64, 4, True, 4, True, 2, 5, 1, "dpp", False, 2, False, "scatter")
+    assert t.cfgToString(v) == t.cfgToString(v + ("taps",)) == "fu3d3bx64y8sn64u4bmx4bmy2mf5pxdm2"
+    assert t.cfgToString(v + ("rows",)) == "fu3d3bx64y8sn64u4bmx4bmy2mf5pxdm2o" and t.cfgToCommandLine(v + ("rows",)).endswith("--schedule scatter --order rows --pack 0")
+    assert t.cfgToString(v + ("rowspk",)).endswith("ok") and t.cfgToString(v + ("pin",)).endswith("k") and t.cfgToCommandLine(v + ("pin",)).endswith("--pin 1")
+    assert t.FilterParams(v + ("rows",)) and not t.FilterParams(v[:15] + ("reuse", "rows")) and not t.FilterParams(v + ("columns",))
+    sp = t.enumerate_space((3,), emits=("rows", "rowspk"))
+    assert sp and all(len(x) == 17 and x[16] in ("rows", "rowspk") and x[15] == "scatter" for x in sp)
+    names = [t.cfgToString(x) for x in sp]
+    assert len(set(names)) == len(names)
+    # a fenced --temporal configuration is a duplicate of its fused twin: dropped before anything is compiled
+    c4 = os.path.join(ROOT, "benchmarks", "configs", "c4_3d7pt_star_1024.stc")
+    assert not t.toleranceFilter(["--3d", "--dtype", "fp32", "--step", "3", "--temporal", "1", c4])
+    assert t.toleranceFilter(["--3d", "--dtype", "fp32", "--step", "2", "--temporal", "1", c4]) and t.toleranceFilter(["--3d", "--dtype", "fp32", "--step", "3", c4])
+    # pinned kernels: the register rule is the generator's named state, not round 2's fitted model
+    assert t.registerFilter(["--3d", "--dtype", "fp32", "--step", "3", "--order", "rows", "--pack", "0", "--prefetch", "--prefetch-depth", "1", "--bx", "64", "--by", "8", "--block-merge-y", "2", c4])
+    assert not t.registerFilter(["--3d", "--dtype", "fp32", "--step", "3", "--order", "rows", "--bx", "32", "--by", "16", "--block-merge-y", "8", c4])

@@ -316,6 +316,8 @@ def _emulated_fuzz_jobs(n=14, seed=9):
                     cl += ["--stage", "dma"]
                 if rnd.random() < 0.3:
                     cl += ["--defer-stores", "1"]          # LDS-DMA staging (16-byte vectors: the generator rejects the others)
+                import fuzz_parity
+                fuzz_parity.round3_knobs(rnd, cl)          # round 3: rows order / packed pairs / pinned sums / rotation modulus / loader wavefronts
                 jobs.append((t.cfgToString(v) + "_" + dtype + "_%dd" % ndim + pts.lower(), ndim, pts, dims, (["--3d"] if ndim == 3 else []) + ["--dtype", dtype] + cl, v[0]))
     return jobs
 
