@@ -86,7 +86,8 @@ TUNED = {
     "s_2d5pt_cross": ["--dtype", "fp64", "--step", "2", "--dist", "2", "--bx", "64", "--by", "4", "--block-merge-x", "2", "--block-merge-y", "4", "--xcd-remap", "0"],
     "s_2d9pt_box": ["--dtype", "fp64", "--step", "2", "--bx", "64", "--by", "4", "--block-merge-x", "2", "--block-merge-y", "4", "--xcd-remap", "0"],
     # 2d9pt_cross (diagonal cross of order 2; the reference's tuner sweeps it at --step 2 --dist 2, benchmarks/2d9pt_cross/tuning.py:127): fused, bit-exact
-    "s_2d9pt_cross": ["--dtype", "fp64", "--step", "2", "--dist", "2", "--bx", "64", "--by", "4", "--block-merge-x", "2", "--block-merge-y", "4", "--xcd-remap", "0"],
+    # (rows order: 746 GStencil/s against 522 for the taps-order kernel of the same geometry, profiles/r03_exp_r3g.log)
+    "s_2d9pt_cross": ["--dtype", "fp64", "--step", "2", "--bx", "64", "--by", "4", "--block-merge-x", "2", "--block-merge-y", "4", "--xcd-remap", "0", "--order", "rows"],
     # the wide stencils (order 2 / 35 fused taps) are fastest as on-chip temporal pipelines; in fp64 those stay within 1e-12 of the fused
     # arithmetic (measured 1.7e-15), the bar the tests and bench.py's verification hold fp64 temporal kernels to
     # round 3: with the emitter in charge of the registers the FUSED (bit-exact) step-2 kernels of 2d9pt_star and 3d9pt_cross are faster than
