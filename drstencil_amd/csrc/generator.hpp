@@ -180,7 +180,7 @@ inline GenResult generate(const std::vector<std::string> &args /* argv[1..] */) 
         else if (a == "--dtype") { if (!str_opt(o.dtype)) break; }
         else if (a == "--xrim") { if (!str_opt(o.xrim)) break; }
         else if (a == "--schedule") { if (!str_opt(o.schedule)) break; o.schedule_set = true; }
-        else if (a == "--order") { if (!str_opt(o.order)) break; }
+        else if (a == "--order") { if (!str_opt(o.order)) break; o.order_set = true; }
         else if (a == "--pack") { if (!int_opt(o.pack, nullptr)) break; }
         else if (a == "--row-fence") { if (!int_opt(o.row_fence, nullptr)) break; }
         else if (a == "--loader-waves") { if (!int_opt(o.loader_waves, nullptr)) break; }
@@ -239,6 +239,15 @@ inline GenResult generate(const std::vector<std::string> &args /* argv[1..] */) 
     if (st.partition_reuse(o.merge_forward) != REUSE_OK) { res.messages += "No data to reuse. You can try another dist.\n"; res.exit_code = 1; return res; }
     st.stream_range();
 
+    // Round 3 default emission (no --order given): the rows order -- plane consumed by source row, partial sums pinned -- where it measured
+    // faster AND is what makes the kernel fit at all: fused 3D stencils beyond 25 taps (--step 3: 256 VGPRs + scratch in the taps order,
+    // 98-114 in the rows order; 1880-2080 against 430 GStencil/s at 1024^3) and one-shot 2D tiles of more than 9 taps (2d25pt_box: +6 %,
+    // profiles/r03_exp_r3d.log).  Everything else keeps round 2's emission, which measured faster there (the memory-bound step-2 headline).
+    if (!o.order_set && !o.ref_defaults && !o.temporal && o.schedule == "scatter" && o.stage == "reg" && std::max(o.bmy, o.cmy) == std::max(o.bmy, 1) &&
+        ((st.ndim == 3 && st.pts.size() > 25) || (st.ndim == 2 && !o.streaming && st.pts.size() > 9))) {
+        o.order = "rows";
+        if (o.pack < 0) o.pack = 0;       // packed pairs buy nothing with four waves per SIMD
+    }
     res.plan = make_plan(st, o, kernel_base_name(stcfile));
     if (!res.plan.error.empty()) { res.messages += "Invalid configuration!\n"; res.exit_code = 255; return res; }
     if (!res.plan.note.empty()) res.messages += "drstencil: note: " + res.plan.note + "\n";

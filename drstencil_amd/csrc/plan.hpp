@@ -127,6 +127,7 @@ struct GenOptions {
     bool schedule_set = false;   // --schedule given (else an explicit --dist selects "reuse")
     // Round 3: the emitter bounds the live ranges itself instead of leaving a straight-line plane body to the compiler's pre-RA scheduler
     // (named state 136 words -> 256 VGPRs + scratch for the fused 63-point stencil).
+    bool order_set = false;      // --order given; else the generator picks rows for fused 3D stencils beyond 25 taps and 2D tile kernels beyond 9 (measured)
     std::string order = "taps";  // scatter schedule, emission order of a plane's FMAs.  taps: every partial sum's chain in one piece, the whole rim
                                  // window read up front (rounds 1-2).  rows: by SOURCE ROW -- the arriving plane is consumed one row at a time
                                  // (the row's own-column vector from registers / one LDS read, its x neighbours by DPP), each row's tap groups

@@ -151,7 +151,12 @@ inline KernelPlan make_plan(const Stencil &st, const GenOptions &o_in, const std
         // a 512-lane workgroup no longer fit 256 registers per lane and spill to scratch: 256 lanes (64 x 4) may use the
         // AGPR half of the register file as well and stay spill-free
         const bool heavy = st.pts.size() > 25;
-        if (heavy && !o.bx_set && !o.by_set) {
+        if (heavy && o.order == "rows" && !o.bx_set && !o.by_set) {
+            // round 3 (rows order, pinned sums: 98-114 VGPRs, two workgroups per CU): best of the 1248-configuration grid on 3d7pt_star 1024^3
+            // step 3 (profiles/r03_tune_c4_s3_rows_grid.txt) and of the fp64 runs (r03_exp_r3f.log): 64 x 8 lanes, 2 rows per lane, 64-plane blocks
+            o.bx = 64; o.by = 8; o.bx_set = o.by_set = true;
+            if (!o.sn_set) { o.sn = 64; o.sn_set = true; }
+        } else if (heavy && !o.bx_set && !o.by_set) {
             if (p.fp32) { o.bx = 64; o.by = 4; }
             else { o.bx = 32; o.by = 8; if (!o.my_set) { o.bmy = 1; o.cmy = 1; o.my_set = true; } }   // fp64: one row per lane (2 rows spill at 512^3)
             o.bx_set = o.by_set = true;

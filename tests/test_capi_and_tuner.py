@@ -93,9 +93,11 @@ def test_kernel_resources_and_scratch_refusal(monkeypatch):
     scratch (it has outgrown the register file: slow, and the only place the round-1 parity fuzz found miscompiled
     kernels); the automatic geometry for the same heavy stencil fits and loads."""
     stc = os.path.join(ROOT, "tests", "stc", "t3_star.stc")
-    k = drs.Kernel(["--3d", "--dtype", "fp32", "--step", "3", stc])                      # 63-point fused stencil, automatic geometry
-    assert k.info["threads"] == 256 and k.resources["scratch_bytes_per_lane"] == 0 and k.resources["vgprs"] > 0
-    spilling = ["--3d", "--dtype", "fp32", "--step", "3", "--bx", "32", "--by", "16", "--block-merge-y", "2", "--prefetch-depth", "3", stc]
+    k = drs.Kernel(["--3d", "--dtype", "fp32", "--step", "3", stc])                      # 63-point fused stencil, automatic geometry and emission
+    # round 3: the rows order with pinned sums, 64 x 8 lanes: two workgroups per CU fit (<= 128 VGPRs); rounds 1-2 needed a 256-lane workgroup
+    assert k.info["threads"] == 512 and k.info["order"] == "rows" and k.resources["scratch_bytes_per_lane"] == 0 and 0 < k.resources["vgprs"] <= 128
+    # the round-2 emission of the same stencil at 512 lanes: the compiler sinks the FMA chains, keeps 7 planes of windows alive and spills
+    spilling = ["--3d", "--dtype", "fp32", "--step", "3", "--order", "taps", "--bx", "32", "--by", "16", "--block-merge-y", "2", "--prefetch-depth", "3", stc]
     monkeypatch.delenv("DRS_ALLOW_SCRATCH", raising=False)
     with pytest.raises(RuntimeError) as e:
         drs.Kernel(spilling)
@@ -269,8 +271,10 @@ def test_round3_emission_knobs_and_tuner_dimension(tmp_path):
         return json.loads(re.search(r'return "(\{.*\})";', src).group(1).replace('\\"', '"')), src
 
     base = ["--3d", "--dtype", "fp32", "--step", "3", "--prefetch", "--prefetch-depth", "1", "--bx", "32", "--by", "8", "--block-merge-y", "2"]
-    i0, s0 = info(base)
+    i0, s0 = info(base + ["--order", "taps"])
     assert (i0["order"], i0["packed"], i0["pinned"], i0["unroll"]) == ("taps", 0, 0, 14) and "DRS_PIN" not in s0
+    assert info(base)[0]["order"] == "rows" and info(base)[0]["packed"] == 0, "a fused stencil beyond 25 taps takes the rows order by default (unpacked)"
+    assert info(["--3d", "--dtype", "fp32", "--step", "2"])[0]["order"] == "taps", "the memory-bound step-2 kernel keeps round 2's emission"
     i1, s1 = info(base + ["--order", "rows"])
     assert (i1["order"], i1["packed"], i1["pinned"]) == ("rows", 1, 1)
     assert i1["unroll"] == 8, "Range 7 rotates through 8 sets with --order rows: 8 plane bodies instead of 14"
@@ -278,7 +282,7 @@ def test_round3_emission_knobs_and_tuner_dimension(tmp_path):
     assert "bound_ctrl" not in s1 and "0x138, 0xf, 0xf, true)" in s1            # DPP moves without an `old` operand
     i2, s2 = info(base + ["--order", "rows", "--pack", "0", "--rot-mod", "-1"])
     assert (i2["packed"], i2["unroll"]) == (0, 14) and "vec2_t" not in s2
-    i3, s3 = info(base + ["--pin", "1", "--rot-mod", "9"])
+    i3, s3 = info(base + ["--order", "taps", "--pin", "1", "--rot-mod", "9"])
     assert (i3["order"], i3["pinned"], i3["unroll"]) == ("taps", 1, 18) and "DRS_PIN(c0_" in s3
     # the gold kernel and the arithmetic never depend on the emission
     gold = lambda src: src[src.index("// naive reference kernel"):src.index("// ---- launch entry points")]
