@@ -36,6 +36,9 @@ EMITTED_PROGRAMS = {
     "3d_step2_fp32": ("t3_star", ["--3d", "--dtype", "fp32", "--step", "2", "--check"]),
     "2d_box25_fp64": ("t2_box25", ["--dtype", "fp64", "--check"]),
     "2d_stream_fp32_step2": ("t2_star", ["--dtype", "fp32", "--streaming", "--step", "2", "--prefetch", "--check"]),
+    # round 3: the default emission of a fused 63-point stencil (rows order, pinned sums), and loader wavefronts behind LDS-DMA staging
+    "3d_step3_fp32_default_rows": ("t3_star", ["--3d", "--dtype", "fp32", "--step", "3", "--check"]),
+    "3d_step2_fp64_loader_waves": ("t3_star", ["--3d", "--dtype", "fp64", "--step", "2", "--stage", "dma", "--loader-waves", "2", "--prefetch-depth", "2", "--sn", "16", "--check"]),
 }
 
 
@@ -58,8 +61,11 @@ def _run_emitted_programs(drs, run_them=True):
             text = "[generator rc=%d]\n%s" % (gen.returncode, gen.stdout)
             if gen.returncode == 0:
                 exe = os.path.join(out, pid)
+                import hashlib
                 body = lambda path: [ln for ln in open(path) if not ln.startswith(("// spec:", "// options:"))]   # banner holds paths
-                fresh = os.path.exists(exe) and os.path.exists(hip) and body(hip) == body(new)
+                digest = hashlib.sha256("".join(body(new)).encode()).hexdigest()
+                sha = os.path.join(out, pid + ".sha256")       # travels with the binary (the cached .hip sources do not: .gpurunignore)
+                fresh = os.path.exists(exe) and os.path.exists(sha) and open(sha).read().strip() == digest
                 os.replace(new, hip)
                 if fresh:       # same source as the binary that travelled with the tree (built by __graft_entry__.build())
                     cc = subprocess.CompletedProcess([], 0, "", "")
@@ -67,6 +73,9 @@ def _run_emitted_programs(drs, run_them=True):
                     cc = subprocess.run(["/opt/rocm/bin/hipcc", "-O3", "--offload-arch=gfx950", "-std=c++17", "-ffp-contract=off",
                                          "-o", exe, hip], capture_output=True, text=True, timeout=300)
                 text += "[hipcc rc=%d]\n%s" % (cc.returncode, cc.stderr[-2000:])
+                if cc.returncode == 0:
+                    with open(sha, "w") as f:
+                        f.write(digest + "\n")
                 if cc.returncode == 0 and run_them:
                     run = subprocess.run([exe], capture_output=True, text=True, timeout=120)
                     text += "[program rc=%d]\n%s%s" % (run.returncode, run.stdout, run.stderr[-1000:])

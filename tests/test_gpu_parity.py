@@ -310,7 +310,7 @@ def test_dpp_wave_shift_semantics(torch_cuda):
     assert torch.equal(o1, o2)
 
 
-@pytest.mark.parametrize("pid", ["3d_step2_fp32", "2d_box25_fp64", "2d_stream_fp32_step2"])
+@pytest.mark.parametrize("pid", ["3d_step2_fp32", "2d_box25_fp64", "2d_stream_fp32_step2", "3d_step3_fp32_default_rows", "3d_step2_fp64_loader_waves"])
 def test_emitted_standalone_program(pid):
     """The reference's process contract end to end: `drstencil ... --check -o x.hip spec.stc`, hipcc,
     run the program, read its stdout protocol (codegen.hpp:554,573,588-589,595,621; common.hpp:99).  The three steps
