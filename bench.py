@@ -153,7 +153,11 @@ FUSED3 = {
 def slab_options(workload, world, weak=False):
     opts = list(TUNED[workload])
     if workload == "c4" and world >= 4 and not weak:
+        # round 3: on 128-plane views the PINNED kernel (122 VGPRs: two workgroups per CU) with 16-plane blocks takes 0.188 ms against 0.200 for
+        # round 2's kernel (profiles/r03_exp_r3h.log), and its short blocks still let the RCCL kernel in beside it
         opts[opts.index("--sn") + 1] = "16"
+        opts[opts.index("--prefetch-depth") + 1] = "2"
+        opts += ["--pin", "1"]
     return opts
 
 
