@@ -210,8 +210,9 @@ def pytest_sessionstart(session):
     jobs = all_build_args()
     for c in golden_cases():
         meta, *_ = load_golden(c)
-        opts, stc = golden_args(c, meta)
-        jobs.append(opts + [stc])
+        for rows in (False, True):
+            opts, stc = golden_args(c, meta, rows=rows)
+            jobs.append(opts + [stc])
     from gpu_cases import stc as stcp, fuzz_sample_jobs
     fuzz_args = [j[3] for j in fuzz_sample_jobs()]     # some of these are refused (scratch spills): not an error
     jobs.append(["--dtype", "fp32", "--streaming", "--xrim", "lds", stcp("t2_box25")])

@@ -225,13 +225,14 @@ def all_build_args():
     return out
 
 
-def golden_args(case, meta):
-    """Options for running a golden fixture case through the HIP path (fp64, like the reference)."""
+def golden_args(case, meta, rows=False):
+    """Options for running a golden fixture case through the HIP path (fp64, like the reference).  rows: round 3's emission (the
+    plane consumed by source row, partial sums pinned) instead of the reuse schedule the fixture's --dist selects."""
     # 3D fused multi-step stencils (27 - 63 taps in fp64) keep 2 rows per lane: with 4 the partial sums spill to scratch and the
     # runtime refuses the kernel; the tile still covers the halo (by * my = 8 > 2 * Halo = 6 at step 3)
     my = "2" if meta["ndim"] == 3 and meta["step"] > 1 else "4"
-    opts = (["--3d"] if meta["ndim"] == 3 else []) + ["--dtype", "fp64", "--step", str(meta["step"]), "--dist", str(meta["macros"]["Dist"]),
-                                                       "--bx", "16", "--by", "4", "--block-merge-x", "2", "--block-merge-y", my, "--sn", "4"]
+    opts = (["--3d"] if meta["ndim"] == 3 else []) + ["--dtype", "fp64", "--step", str(meta["step"])] + \
+        ["--dist", str(meta["macros"]["Dist"])] + (["--schedule", "scatter", "--order", "rows"] if rows else []) + ["--bx", "16", "--by", "4", "--block-merge-x", "2", "--block-merge-y", my, "--sn", "4"]
     return opts, stc("gold_" + case)
 
 

@@ -16,10 +16,11 @@ from helpers import golden_cases, load_golden, write_stc
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+@pytest.mark.parametrize("rows", [False, True], ids=["reuse_schedule", "rows_order"])
 @pytest.mark.parametrize("case", golden_cases())
-def test_emulated_kernel_vs_reference_golden(case, tmp_path):
+def test_emulated_kernel_vs_reference_golden(case, rows, tmp_path):
     meta, a0, a_ref, b_ref = load_golden(case)
-    opts, stc = golden_args(case, meta)
+    opts, stc = golden_args(case, meta, rows=rows)
     lib = build_emulated(tmp_path, stc, opts)
     A = np.ascontiguousarray(a0.copy()); B = np.zeros_like(A)
     n = run_emulated(lib, A, B, meta["iterations"], meta["step"])

@@ -80,16 +80,17 @@ def test_hip_vs_oracle_seeded(torch_cuda, cid, ndim, stc, opts):
     assert np.array_equal(Ag, A_ref) and np.array_equal(Bg, B_ref)
 
 
+@pytest.mark.parametrize("rows", [False, True], ids=["reuse_schedule", "rows_order"])
 @pytest.mark.parametrize("case", golden_cases())
-def test_hip_vs_reference_golden_fixture(torch_cuda, case):
+def test_hip_vs_reference_golden_fixture(torch_cuda, case, rows):
     """HIP path (fp64) against arrays produced by the reference-emitted gold statement.
     The fixtures were computed without FMA contraction, the kernels contract: 1e-12."""
     import drstencil_amd as drs
     torch = torch_cuda
     meta, a0, a_ref, b_ref = load_golden(case)
-    opts, stc = golden_args(case, meta)
+    opts, stc = golden_args(case, meta, rows=rows)
     kern = drs.Kernel(opts + [stc])
-    assert kern.info["halo"] == meta["macros"]["Halo"]
+    assert kern.info["halo"] == meta["macros"]["Halo"] and kern.info["order"] == ("rows" if rows else "taps")
     n, A, B = run_hip(torch, kern, np.ascontiguousarray(a0), np.zeros_like(a0))
     assert n == meta["launches"]
     spec = oracle.Spec(stc, meta["ndim"], meta["step"])
