@@ -47,6 +47,7 @@ def lib():
             getattr(L, n).argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
         L.drso_isa.restype = ctypes.c_char_p
         L.drso_set_threads.argtypes = [ctypes.c_int]
+        L.drso_set_avx512_path.argtypes = [ctypes.c_int]
         _LIB = L
     return _LIB
 
@@ -166,6 +167,11 @@ def usable_cpus():
 
 def set_threads(n):
     lib().drso_set_threads(int(n))
+
+
+def set_avx512_path(on):
+    """Switch the register-blocked AVX-512 path of the contracted sweep on / off (tests compare the two bit for bit)."""
+    lib().drso_set_avx512_path(1 if on else 0)
 
 
 def isa():

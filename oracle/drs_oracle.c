@@ -209,7 +209,114 @@ void drso_fill_random_f32(float *a, size_t n)
 #define DRSO_CLONES
 #endif
 
-#define DEF_SWEEP(NAME, T, FMA)                                                          \
+/* AVX-512 fast path of the contracted sweep (contract == 1: what the HIP kernels compute and what bench.py's cpu_baseline times):
+ * 128 (fp32) / 64 (fp64) points per block live in EIGHT zmm accumulators for the whole tap loop -- the generic path above keeps them
+ * in a stack array and pays two loads and a store per vector FMA.  Same arithmetic, lane for lane: t = c0*a0, then t = fma(ci, ai, t)
+ * in table order (an IEEE fused multiply-add per lane), so the results are bit-identical to the generic path (test_oracle_golden.py
+ * compares the two on every fixture).  Picked at run time when the CPU has avx512f. */
+#if defined(__x86_64__) && defined(__GNUC__) && !defined(__clang__)
+#include <immintrin.h>
+#define DRSO_HAVE_AVX512_PATH 1
+__attribute__((target("avx512f")))
+static void sweep_rows_avx512_f32(const drso_spec *s, const float *src, float *dst, const long *doff, const float *cf)
+{
+    const int H = s->halo, L = s->L, M = s->M, N = s->N, np = s->npts;
+    const int klo = (s->ndim == 3) ? H : 0, khi = (s->ndim == 3) ? L - H : 1;
+    #pragma omp parallel for collapse(2) schedule(static)
+    for (int k = klo; k < khi; k++)
+        for (int j = H; j < M - H; j++) {
+            const size_t row = ((size_t)k * M + j) * N;
+            int i0 = H;
+            for (; i0 + 128 <= N - H; i0 += 128) {
+                const float *c = src + row + i0;
+                __m512 w = _mm512_set1_ps(cf[0]);
+                const float *a = c + doff[0];
+                __m512 t0 = _mm512_mul_ps(w, _mm512_loadu_ps(a)), t1 = _mm512_mul_ps(w, _mm512_loadu_ps(a + 16)), t2 = _mm512_mul_ps(w, _mm512_loadu_ps(a + 32)),
+                       t3 = _mm512_mul_ps(w, _mm512_loadu_ps(a + 48)), t4 = _mm512_mul_ps(w, _mm512_loadu_ps(a + 64)), t5 = _mm512_mul_ps(w, _mm512_loadu_ps(a + 80)),
+                       t6 = _mm512_mul_ps(w, _mm512_loadu_ps(a + 96)), t7 = _mm512_mul_ps(w, _mm512_loadu_ps(a + 112));
+                for (int p = 1; p < np; p++) {
+                    w = _mm512_set1_ps(cf[p]);
+                    a = c + doff[p];
+                    t0 = _mm512_fmadd_ps(w, _mm512_loadu_ps(a), t0); t1 = _mm512_fmadd_ps(w, _mm512_loadu_ps(a + 16), t1);
+                    t2 = _mm512_fmadd_ps(w, _mm512_loadu_ps(a + 32), t2); t3 = _mm512_fmadd_ps(w, _mm512_loadu_ps(a + 48), t3);
+                    t4 = _mm512_fmadd_ps(w, _mm512_loadu_ps(a + 64), t4); t5 = _mm512_fmadd_ps(w, _mm512_loadu_ps(a + 80), t5);
+                    t6 = _mm512_fmadd_ps(w, _mm512_loadu_ps(a + 96), t6); t7 = _mm512_fmadd_ps(w, _mm512_loadu_ps(a + 112), t7);
+                }
+                float *d = dst + row + i0;
+                _mm512_storeu_ps(d, t0); _mm512_storeu_ps(d + 16, t1); _mm512_storeu_ps(d + 32, t2); _mm512_storeu_ps(d + 48, t3);
+                _mm512_storeu_ps(d + 64, t4); _mm512_storeu_ps(d + 80, t5); _mm512_storeu_ps(d + 96, t6); _mm512_storeu_ps(d + 112, t7);
+            }
+            for (; i0 < N - H; i0 += 16) {                       /* the row's tail, 16 points at a time under a mask */
+                const int n = N - H - i0 < 16 ? N - H - i0 : 16;
+                const __mmask16 m = (__mmask16)((1u << n) - 1u);
+                const float *c = src + row + i0;
+                __m512 t = _mm512_mul_ps(_mm512_set1_ps(cf[0]), _mm512_maskz_loadu_ps(m, c + doff[0]));
+                for (int p = 1; p < np; p++) t = _mm512_fmadd_ps(_mm512_set1_ps(cf[p]), _mm512_maskz_loadu_ps(m, c + doff[p]), t);
+                _mm512_mask_storeu_ps(dst + row + i0, m, t);
+            }
+        }
+}
+__attribute__((target("avx512f")))
+static void sweep_rows_avx512_f64(const drso_spec *s, const double *src, double *dst, const long *doff, const double *cf)
+{
+    const int H = s->halo, L = s->L, M = s->M, N = s->N, np = s->npts;
+    const int klo = (s->ndim == 3) ? H : 0, khi = (s->ndim == 3) ? L - H : 1;
+    #pragma omp parallel for collapse(2) schedule(static)
+    for (int k = klo; k < khi; k++)
+        for (int j = H; j < M - H; j++) {
+            const size_t row = ((size_t)k * M + j) * N;
+            int i0 = H;
+            for (; i0 + 64 <= N - H; i0 += 64) {
+                const double *c = src + row + i0;
+                __m512d w = _mm512_set1_pd(cf[0]);
+                const double *a = c + doff[0];
+                __m512d t0 = _mm512_mul_pd(w, _mm512_loadu_pd(a)), t1 = _mm512_mul_pd(w, _mm512_loadu_pd(a + 8)), t2 = _mm512_mul_pd(w, _mm512_loadu_pd(a + 16)),
+                        t3 = _mm512_mul_pd(w, _mm512_loadu_pd(a + 24)), t4 = _mm512_mul_pd(w, _mm512_loadu_pd(a + 32)), t5 = _mm512_mul_pd(w, _mm512_loadu_pd(a + 40)),
+                        t6 = _mm512_mul_pd(w, _mm512_loadu_pd(a + 48)), t7 = _mm512_mul_pd(w, _mm512_loadu_pd(a + 56));
+                for (int p = 1; p < np; p++) {
+                    w = _mm512_set1_pd(cf[p]);
+                    a = c + doff[p];
+                    t0 = _mm512_fmadd_pd(w, _mm512_loadu_pd(a), t0); t1 = _mm512_fmadd_pd(w, _mm512_loadu_pd(a + 8), t1);
+                    t2 = _mm512_fmadd_pd(w, _mm512_loadu_pd(a + 16), t2); t3 = _mm512_fmadd_pd(w, _mm512_loadu_pd(a + 24), t3);
+                    t4 = _mm512_fmadd_pd(w, _mm512_loadu_pd(a + 32), t4); t5 = _mm512_fmadd_pd(w, _mm512_loadu_pd(a + 40), t5);
+                    t6 = _mm512_fmadd_pd(w, _mm512_loadu_pd(a + 48), t6); t7 = _mm512_fmadd_pd(w, _mm512_loadu_pd(a + 56), t7);
+                }
+                double *d = dst + row + i0;
+                _mm512_storeu_pd(d, t0); _mm512_storeu_pd(d + 8, t1); _mm512_storeu_pd(d + 16, t2); _mm512_storeu_pd(d + 24, t3);
+                _mm512_storeu_pd(d + 32, t4); _mm512_storeu_pd(d + 40, t5); _mm512_storeu_pd(d + 48, t6); _mm512_storeu_pd(d + 56, t7);
+            }
+            for (; i0 < N - H; i0 += 8) {
+                const int n = N - H - i0 < 8 ? N - H - i0 : 8;
+                const __mmask8 m = (__mmask8)((1u << n) - 1u);
+                const double *c = src + row + i0;
+                __m512d t = _mm512_mul_pd(_mm512_set1_pd(cf[0]), _mm512_maskz_loadu_pd(m, c + doff[0]));
+                for (int p = 1; p < np; p++) t = _mm512_fmadd_pd(_mm512_set1_pd(cf[p]), _mm512_maskz_loadu_pd(m, c + doff[p]), t);
+                _mm512_mask_storeu_pd(dst + row + i0, m, t);
+            }
+        }
+}
+static int g_avx512_path = -1;     /* -1 unknown, 0 off (DRSO_NO_AVX512_PATH=1 or no avx512f), 1 on */
+static int use_avx512_path(void)
+{
+    if (g_avx512_path < 0) {
+        __builtin_cpu_init();
+        const char *off = getenv("DRSO_NO_AVX512_PATH");
+        g_avx512_path = (__builtin_cpu_supports("avx512f") && !(off && off[0] == '1')) ? 1 : 0;
+    }
+    return g_avx512_path;
+}
+#endif
+void drso_set_avx512_path(int on)
+{
+#ifdef DRSO_HAVE_AVX512_PATH
+    __builtin_cpu_init();
+    g_avx512_path = (on && __builtin_cpu_supports("avx512f")) ? 1 : 0;
+#else
+    (void)on;
+#endif
+}
+
+#define DEF_SWEEP(NAME, T, FMA, FAST)                                                        \
 DRSO_CLONES                                                                              \
 void NAME(const drso_spec *s, const T *src, T *dst, int contract)                       \
 {                                                                                        \
@@ -221,6 +328,7 @@ void NAME(const drso_spec *s, const T *src, T *dst, int contract)               
         doff[p] = ((long)s->off[p][0] * M + s->off[p][1]) * N + s->off[p][2];            \
         cf[p] = (T)s->coef[p];                                                           \
     }                                                                                    \
+    if (contract && FAST(s, src, dst, doff, cf)) { free(doff); free(cf); return; }       \
     _Pragma("omp parallel for collapse(2) schedule(static)")                             \
     for (int k = klo; k < khi; k++)                                                      \
         for (int j = H; j < M - H; j++) {                                                \
@@ -228,7 +336,7 @@ void NAME(const drso_spec *s, const T *src, T *dst, int contract)               
             for (int i0 = H; i0 < N - H; i0 += DRSO_BLK) {                               \
                 const int n = (N - H - i0 < DRSO_BLK) ? N - H - i0 : DRSO_BLK;           \
                 const T *c = src + row + i0;                                             \
-                T t[DRSO_BLK];                                                           \
+                T t[DRSO_BLK] __attribute__((aligned(64)));                                \
                 {                                                                        \
                     const T *a = c + doff[0]; const T w = cf[0];                         \
                     for (int x = 0; x < n; x++) t[x] = w * a[x];                         \
@@ -250,8 +358,15 @@ void NAME(const drso_spec *s, const T *src, T *dst, int contract)               
     free(doff); free(cf);                                                                \
 }
 
-DEF_SWEEP(drso_sweep_f64, double, __builtin_fma)
-DEF_SWEEP(drso_sweep_f32, float, __builtin_fmaf)
+#ifdef DRSO_HAVE_AVX512_PATH
+static int fast_f64(const drso_spec *s, const double *src, double *dst, const long *doff, const double *cf) { if (!use_avx512_path()) return 0; sweep_rows_avx512_f64(s, src, dst, doff, cf); return 1; }
+static int fast_f32(const drso_spec *s, const float *src, float *dst, const long *doff, const float *cf) { if (!use_avx512_path()) return 0; sweep_rows_avx512_f32(s, src, dst, doff, cf); return 1; }
+#else
+#define fast_f64(s, a, b, c, d) 0
+#define fast_f32(s, a, b, c, d) 0
+#endif
+DEF_SWEEP(drso_sweep_f64, double, __builtin_fma, fast_f64)
+DEF_SWEEP(drso_sweep_f32, float, __builtin_fmaf, fast_f32)
 
 /* The pages of a freshly allocated (untouched) array are placed on the NUMA node of the thread that writes them first:
  * zero-fill with the sweep's own (k, j) schedule, whole rows including the ring. */
@@ -356,7 +471,7 @@ const char *drso_isa(void)
 {
 #if defined(__x86_64__) && defined(__GNUC__) && !defined(__clang__)
     __builtin_cpu_init();
-    if (__builtin_cpu_supports("avx512f")) return "avx512f";
+    if (__builtin_cpu_supports("avx512f")) return use_avx512_path() ? "avx512f (register-blocked intrinsics)" : "avx512f";
     if (__builtin_cpu_supports("avx2") && __builtin_cpu_supports("fma")) return "avx2+fma";
 #endif
     return "baseline";

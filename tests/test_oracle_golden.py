@@ -141,3 +141,33 @@ def test_random_shapes_against_the_reference_binary():
     p = subprocess.run([sys.executable, os.path.join(root, "oracle", "fuzz_vs_reference.py"), "40", "7", "8"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
     assert p.returncode == 0 and " 0 DIFFERENCES" in p.stdout, p.stdout[-2000:]
     assert "bit for bit on 8 of 8 sampled cases" in p.stdout, p.stdout[-600:]
+
+
+def test_avx512_fast_path_equals_the_generic_sweep(tmp_path):
+    """The contracted sweep has a register-blocked AVX-512 path (oracle/drs_oracle.c: eight zmm accumulators per block of 128 / 64 points,
+    masked tail) next to the generic, auto-vectorised one that the golden fixtures pin.  Same chain per point -- t = c0*a0, t = fma(ci, ai, t)
+    in table order -- so the two must agree BIT FOR BIT, on ragged sizes (tails of 1 ... 15 points), both dtypes, 2D and 3D, steps 1-3."""
+    from helpers import write_stc
+    if "register-blocked" not in oracle.isa():
+        pytest.skip("no avx512f on this host: the generic path is the only one")
+    rng = np.random.default_rng(3)
+    star3 = [(0, 0, 0, 0.3), (1, 0, 0, 0.2), (-1, 0, 0, 0.15), (0, 1, 0, 0.2), (0, -1, 0, 0.1), (0, 0, 1, 0.25), (0, 0, -1, 0.2)]
+    box2 = [(j, i, round(0.01 + 0.01 * ((j + 2) * 5 + i + 2), 2)) for j in range(-2, 3) for i in range(-2, 3)]
+    cases = [(3, star3, (9, 11, 130 + 7), 1), (3, star3, (11, 13, 257), 2), (3, star3, (13, 15, 129 + 6 + 15), 3), (2, box2, (1, 23, 64 + 4 + 1), 1),
+             (2, box2, (1, 19, 300), 2), (3, star3, (7, 9, 7), 1)]
+    try:
+        for ndim, pts, dims, step in cases:
+            stc = str(tmp_path / ("f%d_%d.stc" % (ndim, dims[2])))
+            write_stc(stc, ndim, dims, 4, pts)
+            spec = oracle.Spec(stc, ndim, step)
+            for dt in (np.float32, np.float64):
+                a = rng.random(spec.shape).astype(dt)
+                out = []
+                for on in (1, 0):
+                    oracle.set_avx512_path(on)
+                    b = np.full_like(a, 7.0)             # the ring must stay untouched by both paths
+                    oracle.sweep(spec, a, b, contract=1)
+                    out.append(b)
+                assert np.array_equal(out[0], out[1]), (ndim, dims, step, dt)
+    finally:
+        oracle.set_avx512_path(1)
