@@ -130,6 +130,8 @@ WINDOW2WG = {
 _S3 = ["--3d", "--dtype", "fp32", "--step", "3", "--prefetch", "--prefetch-depth", "1", "--block-merge-x", "4", "--order", "rows", "--pack", "0", "--cc-opt", "-fno-slp-vectorize"]
 FUSED3 = {
     "c4": [_S3 + ["--bx", "64", "--by", "8", "--block-merge-y", "2", "--sn", "64", "--xcd-remap", "2"],
+           _S3 + ["--bx", "64", "--by", "8", "--block-merge-y", "2", "--sn", "128", "--xcd-remap", "2"],       # the best on the slowest box seen (r03_exp_r3c.log)
+           [x for x in _S3 if x not in ("--pack", "0", "--cc-opt", "-fno-slp-vectorize")] + ["--bx", "64", "--by", "8", "--block-merge-y", "2", "--sn", "64", "--xcd-remap", "2"],   # packed pairs
            _S3 + ["--bx", "128", "--by", "4", "--block-merge-y", "2", "--sn", "128", "--xcd-remap", "2"],
            _S3 + ["--bx", "64", "--by", "16", "--block-merge-y", "1", "--sn", "128", "--xcd-remap", "2"],      # one 1024-lane workgroup per CU: every CU on the same stream block
            _S3 + ["--bx", "32", "--by", "16", "--block-merge-y", "2", "--sn", "64", "--xcd-remap", "0"]],
@@ -392,6 +394,9 @@ def parse_args(argv=None):
     ap.add_argument("--slab-runtime", default="torch", choices=["torch", "native"],
                     help="N > 1: torch = drstencil_amd.multigpu.SlabRun (torch.distributed send/recv; the reference implementation); native = the "
                          "C ABI's drs_slab_* entry points (RCCL called directly, one ping-pong pair captured into a HIP graph)")
+    ap.add_argument("--placement", default="measured", choices=["measured", "kernel", "separate"],
+                    help="N = 1: where the output array sits relative to the input array (launch time depends on (out - in) mod 64 MiB): measured on "
+                         "this device before the timed region (default), the kernel's own recommendation, or two separate allocations")
     ap.add_argument("--headline-only", action="store_true", help="skip the side measurements (profiling runs: one dr_ kernel in the trace)")
     ap.add_argument("--no-verify", action="store_true", help="skip the post-loop comparison of the timed kernel with the gold kernel and the oracle")
     ap.add_argument("--n1-value", type=float, default=None, help="N > 1: the N = 1 value of the same workload; the line then carries value / (N * n1) as efficiency_vs_n1")
@@ -583,8 +588,22 @@ def main(argv=None):
     if pworld == 1:
         g = torch.Generator(device=dev).manual_seed(1)
         shape = (L, M, N) if w["ndim"] == 3 else (M, N)
-        A = torch.rand(shape, dtype=tdt, device=dev, generator=g)
-        B = torch.zeros_like(A)
+        # Both arrays in ONE allocation, the output placed relative to the input: a z-streaming kernel's launch time depends on
+        # (out - in) mod 64 MiB (profiles/r03_probe_skew4.log: C4 headline 1.47 ms in the good half of the period, 1.65-1.68 in the worst
+        # eighth).  --placement measured (default): the position is measured on this device before anything is timed; kernel: the
+        # generator's recommendation (kernel info out_skew_bytes); separate: two independent allocations, as rounds 1-2 did
+        placement = {"mode": args.placement}
+        if args.placement == "separate":
+            A = torch.rand(shape, dtype=tdt, device=dev, generator=g)
+            B = torch.zeros_like(A)
+        else:
+            A, B, _arena = kern.alloc_pair(torch, dev, dtype=tdt, calibrate=(args.placement == "measured"))
+            A.copy_(torch.rand(shape, dtype=tdt, device=dev, generator=g))
+            B.zero_()
+            placement.update({"out_minus_in_mod_period_bytes": kern.pair_skew_bytes, "period_bytes": kern.info.get("placement_period_bytes"),
+                              "kernel_recommendation_bytes": kern.info.get("out_skew_bytes")})
+            if args.placement == "measured":
+                placement["measured_ms_fwd_bwd_by_skew_MiB"] = {str(sk >> 20): [round(f, 4), round(b, 4)] for sk, f, b in kern.skew_calibration}
         stream = torch.cuda.current_stream(dev)
         for _ in range(args.warmup):
             kern.run(A.data_ptr(), B.data_ptr(), iterations=iters, stream=stream.cuda_stream)
@@ -764,6 +783,8 @@ def main(argv=None):
             "verification": verification,
             "device": device_info(torch, dev),
         }
+        if pworld == 1:
+            out["config"]["placement"] = placement
         if pworld > 1:
             out["rank_ms_per_step"] = rank_ms_per_step
             if n1_value:

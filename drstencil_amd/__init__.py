@@ -56,6 +56,8 @@ def lib():
     L.drs_kernel_path.argtypes = [vp]
     L.drs_kernel_resources.restype = ctypes.c_char_p
     L.drs_kernel_resources.argtypes = [vp]
+    L.drs_kernel_pair_layout.restype = ctypes.c_int
+    L.drs_kernel_pair_layout.argtypes = [vp, ctypes.POINTER(ctypes.c_size_t), ctypes.POINTER(ctypes.c_size_t)]
     L.drs_kernel_launch.argtypes = [vp, vp, vp, vp]
     L.drs_kernel_launch_gold.argtypes = [vp, vp, vp, vp]
     L.drs_kernel_launch_pair.argtypes = [vp, vp, vp, vp, vp, vp]
@@ -89,7 +91,7 @@ EXPORTS = [
     "drs_version", "drs_free", "drs_generate",
     "drs_spec_open", "drs_spec_close", "drs_spec_halo", "drs_spec_dist", "drs_spec_range", "drs_spec_npoints",
     "drs_spec_iterations", "drs_spec_launches", "drs_spec_dims", "drs_spec_point", "drs_spec_partition",
-    "drs_kernel_build", "drs_kernel_close", "drs_kernel_unload", "drs_kernel_info", "drs_kernel_path", "drs_kernel_resources", "drs_kernel_launch", "drs_kernel_launch_pair",
+    "drs_kernel_build", "drs_kernel_close", "drs_kernel_unload", "drs_kernel_info", "drs_kernel_path", "drs_kernel_resources", "drs_kernel_pair_layout", "drs_kernel_launch", "drs_kernel_launch_pair",
     "drs_kernel_launch_gold", "drs_kernel_run", "drs_kernel_run_timed",
     "drs_fill_random_f64", "drs_fill_random_f32", "drs_check_error_f64", "drs_check_error_f32",
     "drs_slab_unique_id", "drs_slab_open", "drs_slab_plan", "drs_slab_connect", "drs_slab_run", "drs_slab_sync", "drs_slab_stream", "drs_slab_info",
@@ -261,6 +263,73 @@ class Kernel:
         i = self.info
         pts = i["M"] * i["N"] * (i["L"] if i["ndim"] == 3 else 1)
         return 2 * (4 if i["dtype"] == "fp32" else 8) * pts
+
+    # ---- placement of the output array (csrc/emit_hip.hpp: out_skew_bytes; profiles/r03_probe_skew4.log) ----
+    def array_bytes(self):
+        return self.bytes_per_launch() // 2
+
+    def pair_layout(self, skew=None):
+        """(arena bytes, byte offset of the output array) for both arrays of this kernel in ONE allocation: the output starts
+        `skew` bytes (default: the kernel's own recommendation, info["out_skew_bytes"]) past a multiple of the 64 MiB placement
+        period behind the input.  A z-streaming kernel's launch time depends on (out - in) mod 64 MiB by up to 14 %."""
+        period = int(self.info.get("placement_period_bytes", 64 << 20))
+        skew = int(self.info.get("out_skew_bytes", 0)) if skew is None else int(skew)
+        nb = self.array_bytes()
+        off = -(-nb // period) * period + skew % period
+        return off + nb, off
+
+    def alloc_pair(self, torch, device, dtype=None, skew=None, calibrate=False, stream=0):
+        """Both arrays of the kernel's grid as views of one torch allocation laid out by pair_layout(): (A, B, arena).  With
+        calibrate=True the skew is MEASURED on this device instead (both directions of the ping-pong at eight positions, a few
+        launches each, contents undefined afterwards) -- the kernel's recommendation is a model, the arena has room for any skew."""
+        i = self.info
+        dtype = dtype or (torch.float32 if i["dtype"] == "fp32" else torch.float64)
+        shape = (i["L"], i["M"], i["N"]) if i["ndim"] == 3 else (i["M"], i["N"])
+        period = int(i.get("placement_period_bytes", 64 << 20))
+        nb = self.array_bytes()
+        base_off = -(-nb // period) * period
+        arena = torch.empty(base_off + period + nb, dtype=torch.uint8, device=device)
+        if calibrate:
+            arena.zero_()
+            skew, table = self.calibrate_skew(torch, arena.data_ptr(), arena.data_ptr() + base_off, period, stream=stream)
+            self.skew_calibration = table
+        elif skew is None:
+            skew = int(i.get("out_skew_bytes", 0))
+        off = base_off + int(skew) % period
+        n = nb // arena.new_empty(0, dtype=dtype).element_size()
+        A = arena[:nb].view(dtype).view(shape)
+        B = arena[off:off + nb].view(dtype).view(shape)
+        assert A.numel() == n and B.data_ptr() - A.data_ptr() == off
+        self.pair_skew_bytes = int(skew) % period
+        return A, B, arena
+
+    def calibrate_skew(self, torch, d_in, d_out0, period, steps=4, launches=4, stream=0):
+        """Time in -> out and out -> in for out = d_out0 + j * period / steps; returns (best skew in bytes, [(skew, ms fwd, ms bwd)]).
+        Four positions, 16 MiB apart: kernels with several z fronts in flight (16 MiB apart for the full-row step-1 kernel) dislike odd
+        multiples of 8 MiB, and the single-front kernels' good zone is 24 MiB wide (profiles/r03_probe_skew5.log).  A position within
+        0.5 % of the best that equals the kernel's own recommendation wins (noise must not move it)."""
+        st = torch.cuda.current_stream() if not stream else None
+        s = st.cuda_stream if st is not None else stream
+        e = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+        table = []
+        for j in range(steps):
+            d_out = d_out0 + j * (period // steps)
+            self.launch(d_in, d_out, s); self.launch(d_out, d_in, s)
+            e[0].record(st) if st is not None else e[0].record()
+            for _ in range(launches):
+                self.launch(d_in, d_out, s)
+            e[1].record(st) if st is not None else e[1].record()
+            for _ in range(launches):
+                self.launch(d_out, d_in, s)
+            e[2].record(st) if st is not None else e[2].record()
+            torch.cuda.synchronize()
+            table.append((j * (period // steps), e[0].elapsed_time(e[1]) / launches, e[1].elapsed_time(e[2]) / launches))
+        best = min(table, key=lambda r: r[1] + r[2])
+        rec = int(self.info.get("out_skew_bytes", 0)) % period
+        for r in table:
+            if r[0] == rec and r[1] + r[2] <= 1.005 * (best[1] + best[2]):
+                best = r
+        return best[0], table
 
     def close(self):
         """Release the handle; the plugin stays mapped (see the class docstring)."""

@@ -370,6 +370,22 @@ const char *drs_kernel_info(const drs_kernel *k) { return k->info(); }
 const char *drs_kernel_path(const drs_kernel *k) { return k->path.c_str(); }
 const char *drs_kernel_resources(const drs_kernel *k) { return k->resources.c_str(); }
 
+// Both arrays of the kernel's grid in ONE allocation: the output starts `out_offset` bytes behind the input, i.e. the kernel's
+// recommended skew (info: out_skew_bytes) past a multiple of the placement period (64 MiB) that clears the input array.
+int drs_kernel_pair_layout(const drs_kernel *k, size_t *arena_bytes, size_t *out_offset) {
+    if (!k || !k->info) return -1;
+    const std::string info = k->info();
+    auto num = [&](const char *key, long dflt) { long v = remark_value(info, key); return v < 0 ? dflt : v; };
+    const long L = num("\"L\":", 1), M = num("\"M\":", 1), N = num("\"N\":", 1), ndim = num("\"ndim\":", 3);
+    const size_t esz = info.find("\"dtype\":\"fp32\"") != std::string::npos ? 4 : 8;
+    const size_t nbytes = esz * (size_t)M * (size_t)N * (size_t)(ndim == 3 ? L : 1);
+    const size_t period = (size_t)num("\"placement_period_bytes\":", 64L << 20), skew = (size_t)num("\"out_skew_bytes\":", 0);
+    const size_t off = (nbytes + period - 1) / period * period + skew % period;
+    if (arena_bytes) *arena_bytes = off + nbytes;
+    if (out_offset) *out_offset = off;
+    return 0;
+}
+
 int drs_kernel_launch(drs_kernel *k, const void *d_in, void *d_out, void *stream) {
     g_launched = true;
     return k->launch(d_in, d_out, (hipStream_t)stream);

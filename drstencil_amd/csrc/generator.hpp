@@ -95,6 +95,13 @@ MI355X options:
                         loop is unrolled by lcm(n, LDS slots, prefetch sets): e.g. Range 7 -> 14 plane bodies, --rot-mod 8 -> 8
                         (code size; the instruction cache holds 64 KB).
 --row-fence <mask>      sched_barrier mask between row groups (0 default: nothing crosses; -1: no fence).
+--out-skew <MiB>        Placement of the output array relative to the input array: (out - in) mod 64 MiB.  A z-streaming kernel reads a few
+                        planes ahead of the plane it writes; when its writes land, modulo 64 MiB, 8-16 MiB behind its read front the launch
+                        takes up to 14 % longer on MI355X (profiles/r03_probe_skew4.log).  Default: chosen from the kernel's read-ahead
+                        distance (32 or 0).  The emitted program allocates both arrays in one arena accordingly; callers of the C ABI
+                        read the recommendation from the kernel info (out_skew_bytes, placement_period_bytes).  Results never depend on it.
+--coef <lit|sgpr|vgpr>  fp32: coefficients as 32-bit literals of every FMA (lit, default) or held in scalar registers (sgpr: 4-byte
+                        instead of 8-byte FMAs -- code size and instruction fetch of the fused multi-step kernels; same results).
 --temporal <0|1|force>  With --step n > 1: run the one-step stencil n times on chip (temporal blocking,
                         intermediate planes never leave the CU) instead of the fused stencil.  On-chip stages
                         re-associate the fused sum: 1 emits them only where the estimated drift from the reference's
@@ -183,6 +190,15 @@ inline GenResult generate(const std::vector<std::string> &args /* argv[1..] */) 
         else if (a == "--order") { if (!str_opt(o.order)) break; o.order_set = true; }
         else if (a == "--pack") { if (!int_opt(o.pack, nullptr)) break; }
         else if (a == "--row-fence") { if (!int_opt(o.row_fence, nullptr)) break; }
+        else if (a == "--out-skew") { if (!int_opt(o.out_skew, nullptr)) break; }
+        else if (a == "--coef") {
+            std::string v;
+            if (!str_opt(v)) break;
+            if (v == "sgpr") o.coef_sgpr = 1;
+            else if (v == "vgpr") o.coef_sgpr = 2;
+            else if (v == "lit") o.coef_sgpr = 0;
+            else { res.messages += "Illegal input.\n"; res.exit_code = 255; return res; }
+        }
         else if (a == "--loader-waves") { if (!int_opt(o.loader_waves, nullptr)) break; }
         else if (a == "--rot-mod") { if (!int_opt(o.rot_mod, nullptr)) break; }
         else if (a == "--pin") { if (!int_opt(o.pin, nullptr)) break; }

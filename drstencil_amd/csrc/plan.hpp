@@ -145,6 +145,10 @@ struct GenOptions {
                                  // other use -- and keeps the SOURCE windows of all those planes alive instead of one partial sum (seen in the
                                  // ISA: one mul + 62 FMAs on one register pair right in front of the store, 370 live values for 136 named
                                  // ones, profiles/r03_sinking.md).  The pin makes each update used where it is written.  -1 auto: on with --order rows
+    int out_skew = -1;           // --out-skew <MiB>: where the output array should sit relative to the input array, modulo 64 MiB (see
+                                 // HipEmitter::out_skew_bytes; -1: chosen by the generator).  It changes no kernel text: the value is published
+                                 // in the info JSON / the banner and honoured by the emitted host program, which owns its allocations
+    int coef_sgpr = 0;           // --coef sgpr: fp32 coefficient values in scalar registers instead of 32-bit literals (4-byte instead of 8-byte FMAs)
     int row_fence = 0;           // mask of __builtin_amdgcn_sched_barrier between row groups (0: nothing crosses; -1: no fence)
 };
 

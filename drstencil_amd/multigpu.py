@@ -258,6 +258,31 @@ class HipSweep:
         k.launch(src_view.data_ptr(), dst_view.data_ptr(), stream)
 
 
+
+PLACEMENT_PERIOD = 64 << 20      # csrc/emit_hip.hpp: kPlacementPeriod
+
+
+def slab_pair(torch, shape, dtype, device, skew=None):
+    """The two slab arrays (zero-filled).  On a GPU they are views of ONE allocation with the output `skew` bytes past a multiple of
+    the 64 MiB placement period behind the input (launch time of a z-streaming kernel depends on (out - in) mod 64 MiB,
+    profiles/r03_probe_skew4.log; default 32 MiB when a plane is 2 MiB or more, DRS_SLAB_SKEW_MIB overrides); on the CPU (gloo tests)
+    two plain tensors.  Returns (A, B, arena)."""
+    import os
+    if getattr(device, "type", str(device)) != "cuda":
+        return torch.zeros(shape, dtype=dtype, device=device), torch.zeros(shape, dtype=dtype, device=device), None
+    esz = torch.empty(0, dtype=dtype).element_size()
+    n = 1
+    for d in shape:
+        n *= d
+    nb = n * esz
+    plane = nb // shape[0] if len(shape) == 3 else 0
+    if skew is None:
+        env = os.environ.get("DRS_SLAB_SKEW_MIB")
+        skew = (int(env) << 20) if env else ((32 << 20) if plane >= (2 << 20) else 0)
+    off = -(-nb // PLACEMENT_PERIOD) * PLACEMENT_PERIOD + skew % PLACEMENT_PERIOD
+    arena = torch.zeros(off + nb, dtype=torch.uint8, device=device)
+    return arena[:nb].view(dtype).view(shape), arena[off:off + nb].view(dtype).view(shape), arena
+
 class SlabRun:
     """One rank of a z-slab decomposed run.
 
@@ -276,8 +301,7 @@ class SlabRun:
         self.device, self.dtype = device, dtype
         self.gpu = (device.type == "cuda")
         p = self.plan
-        self.A = torch.zeros((p.Lloc,) + self.rest, dtype=dtype, device=device)
-        self.B = torch.zeros((p.Lloc,) + self.rest, dtype=dtype, device=device)
+        self.A, self.B, self._arena = slab_pair(torch, (p.Lloc,) + self.rest, dtype, device)
         if self.gpu:
             self.main = torch.cuda.current_stream(device)
             self.side = torch.cuda.Stream(device=device, priority=-1)
@@ -397,8 +421,7 @@ class NativeSlabRun:
                              rehearse_world=rehearse_world, cache_dir=cache_dir)
         p = self.plan
         assert (self.slab.lo, self.slab.hi, self.slab.z0, self.slab.z1, self.slab.Lloc) == (p.lo, p.hi, p.z0, p.z1, p.Lloc)
-        self.A = torch.zeros((p.Lloc,) + self.rest, dtype=dtype, device=device)
-        self.B = torch.zeros((p.Lloc,) + self.rest, dtype=dtype, device=device)
+        self.A, self.B, self._arena = slab_pair(torch, (p.Lloc,) + self.rest, dtype, device)
         # the communicator id: made by rank 0, carried by whatever the host has (here: the torch process group)
         if rehearse_world or world == 1:
             uid = drs.slab_unique_id()

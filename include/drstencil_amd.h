@@ -73,6 +73,12 @@ const char *drs_kernel_path(const drs_kernel *k);   /* the loaded shared object 
  * DRS_NO_COMPILE=1 (hipcc is a child process: build first, launch afterwards), and --debug-drop-barrier kernels
  * (wrong results by design) without DRS_EXPERIMENTS=1. */
 const char *drs_kernel_resources(const drs_kernel *k);
+/* Where to put the two arrays.  The reference's host code makes two cudaMalloc calls (codegen.hpp:556-566); on MI355X the
+ * launch time of a z-streaming kernel depends on (out - in) mod 64 MiB -- up to 14 % for the 1024^3 step-2 kernel
+ * (profiles/r03_probe_skew4.log) -- so the emitted program and bench.py carve both arrays out of ONE allocation:
+ * in = arena, out = arena + *out_offset (a multiple of the 64 MiB period that clears the array + the kernel's "out_skew_bytes"),
+ * arena of *arena_bytes.  Advice only: every entry point accepts any two device pointers, results never depend on them. */
+int drs_kernel_pair_layout(const drs_kernel *k, size_t *arena_bytes, size_t *out_offset);
 /* one launch of dr_<name><<<grid, block, 0, stream>>>(in, out): codegen.hpp:577,582-583 */
 int drs_kernel_launch(drs_kernel *k, const void *d_in, void *d_out, void *stream);
 /* one launch of dr2_<name>: the same sweep over TWO (in, out) pairs (kernels generated with --pair-launch 1; -2 otherwise).

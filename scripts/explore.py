@@ -117,12 +117,25 @@ def main():
       for (name, ndim, d, dtype, args), k in kerns:
           key = (tuple(d), dtype)
           if key not in bufs:
-              bufs.clear()
-              torch.cuda.empty_cache()
+              # Buffers live for the whole run (288 GB of HBM): until this round's fix they were re-allocated whenever the grid changed, i.e.
+              # once per round and grid, and the first ~140 ms of launches on a FRESH pair of 4 GiB arrays run the fused step-3 kernels
+              # 15-20 % slower (scripts/probe_cold.py) -- what earlier logs read as a configuration or a device being slow was the
+              # position of the line in the file.  Both arrays sit in one arena at the first kernel's recommended skew, and every
+              # pair is warmed for EXPLORE_WARM_S (default 0.4 s) before its first timing.
               tdt = torch.float32 if dtype == "fp32" else torch.float64
-              shape = tuple(d) if ndim == 3 else tuple(d[1:])
-              bufs[key] = (torch.rand(shape, dtype=tdt, device="cuda"), torch.zeros(shape, dtype=tdt, device="cuda"))
-          A, B = bufs[key]
+              if os.environ.get("EXPLORE_SEPARATE"):
+                  shape = tuple(d) if ndim == 3 else tuple(d[1:])
+                  pair = (torch.rand(shape, dtype=tdt, device="cuda"), torch.zeros(shape, dtype=tdt, device="cuda"), None)
+              else:
+                  pair = k.alloc_pair(torch, "cuda", dtype=tdt, skew=int(os.environ["EXPLORE_SKEW_MIB"]) << 20 if os.environ.get("EXPLORE_SKEW_MIB") else None)
+                  pair[0].uniform_(); pair[1].zero_()
+              bufs[key] = pair
+              tw = time.time()
+              while time.time() - tw < float(os.environ.get("EXPLORE_WARM_S", "0.4")) and not name.startswith("gold"):
+                  for _ in range(4):
+                      k.launch(pair[0].data_ptr(), pair[1].data_ptr()); k.launch(pair[1].data_ptr(), pair[0].data_ptr())
+                  torch.cuda.synchronize()
+          A, B = bufs[key][:2]
           if name.startswith("gold"):
               for _ in range(2):
                   k.launch_gold(A.data_ptr(), B.data_ptr())

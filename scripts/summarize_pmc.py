@@ -77,6 +77,12 @@ for f in sorted(glob.glob(os.path.join(root, "*/*/*counter_collection.csv"))):
         if not r["Kernel_Name"].startswith("dr_"):
             continue
         acc.setdefault(r["Counter_Name"], []).append((int(r["Dispatch_Id"]), float(r["Counter_Value"])))
+        if r["Counter_Name"] == "GRBM_GUI_ACTIVE" and r.get("Start_Timestamp") and r.get("End_Timestamp"):
+            # effective clock of THIS dispatch in THIS (profiled) pass: rocprofv3 reports the sum over the 8 XCDs (MI355X_MICROARCH.md, DVFS give-back)
+            ns = int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
+            if ns > 0:
+                acc.setdefault("effective_clock_GHz_grbm_pass", []).append((int(r["Dispatch_Id"]), float(r["Counter_Value"]) / 8.0 / ns))
+                acc.setdefault("grbm_pass_launch_ns", []).append((int(r["Dispatch_Id"]), float(ns)))
         out.setdefault("vgpr", r["VGPR_Count"]); out.setdefault("lds", r["LDS_Block_Size"])
         out.setdefault("grid", r["Grid_Size"]); out.setdefault("wg", r["Workgroup_Size"])
     for k, v in acc.items():
@@ -94,6 +100,8 @@ if "FETCH_SIZE" in out and "WRITE_SIZE" in out and not ({"fetch", "write"} & set
     out["traffic_bytes_per_launch"] = out["fetch_bytes_corrected_x2"] + out["write_bytes"]
     if "algorithmic_bytes_per_launch" in out:
         out["traffic_over_algorithmic"] = out["traffic_bytes_per_launch"] / out["algorithmic_bytes_per_launch"]
+if "GRBM_GUI_ACTIVE" in out and "effective_clock_GHz_grbm_pass" not in out and out.get("timed_avg_ns"):
+    out["effective_clock_GHz_vs_trace_pass"] = out["GRBM_GUI_ACTIVE"] / 8.0 / out["timed_avg_ns"]     # cycles of one pass over the duration of another: +-3 %
 if "TCC_HIT_sum" in out:
     out["l2_hit_rate"] = out["TCC_HIT_sum"] / (out["TCC_HIT_sum"] + out["TCC_MISS_sum"])
 if "SQ_WAIT_ANY" in out and "SQ_WAVE_CYCLES" in out:
@@ -105,5 +113,5 @@ if "TCC_EA0_RDREQ_LEVEL_sum" in out and out.get("TCC_EA0_RDREQ_sum"):
     out["ea_write_latency_cycles"] = out["TCC_EA0_WRREQ_LEVEL_sum"] / max(out["TCC_EA0_WRREQ_sum"], 1)
 json.dump(out, open(os.path.join("gpurun_out", tag + "_counters.json"), "w"), indent=1)
 keys = ("kernel", "timed_avg_ns", "timed_min_ns", "timed_median_ns", "bench_avg_launch_ms_same_run_hip_events", "timed_avg_over_hip_events", "traffic_over_algorithmic", "l2_hit_rate",
-        "wait_any_frac", "lds_conflict_frac", "ea_read_latency_cycles", "ea_write_latency_cycles", "vgpr")
+        "wait_any_frac", "lds_conflict_frac", "effective_clock_GHz_grbm_pass", "grbm_pass_launch_ns", "effective_clock_GHz_vs_trace_pass", "ea_read_latency_cycles", "ea_write_latency_cycles", "vgpr")
 print(json.dumps({k: out[k] for k in keys if k in out}))

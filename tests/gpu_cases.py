@@ -87,6 +87,8 @@ _add("3dodd_fp64_defer_stores_dma", 3, "t3_odd", "--dtype", "fp64", "--stage", "
 _add("3d7_fp32_s2_rows_packed", 3, "t3_star", "--dtype", "fp32", "--step", "2", "--sn", "16", "--prefetch", "--order", "rows")
 _add("3d7_fp32_s3_rows_packed_pd2", 3, "t3_star", "--dtype", "fp32", "--step", "3", "--sn", "16", "--prefetch", "--prefetch-depth", "2", "--order", "rows", "--bx", "32", "--by", "16", "--block-merge-y", "2")
 _add("3d7_fp32_s3_rows_unpacked", 3, "t3_star", "--dtype", "fp32", "--step", "3", "--sn", "16", "--prefetch", "--order", "rows", "--pack", "0", "--bx", "32", "--by", "16", "--block-merge-y", "2")
+_add("3d7_fp32_s3_rows_coef_sgpr", 3, "t3_star", "--dtype", "fp32", "--step", "3", "--sn", "16", "--prefetch", "--order", "rows", "--pack", "0", "--coef", "sgpr", "--bx", "32", "--by", "16", "--block-merge-y", "2")
+_add("3d7_fp32_s2_taps_coef_vgpr", 3, "t3_star", "--dtype", "fp32", "--step", "2", "--sn", "16", "--prefetch", "--coef", "vgpr")
 _add("3d7_fp64_s2_rows", 3, "t3_star", "--dtype", "fp64", "--step", "2", "--sn", "16", "--order", "rows")
 _add("3d7_fp32_s1_rows_oddN", 3, "t3_star_odd", "--dtype", "fp32", "--order", "rows")
 _add("3d7_fp32_s2_rows_lds_nofence", 3, "t3_star", "--dtype", "fp32", "--step", "2", "--sn", "9", "--xrim", "lds", "--order", "rows", "--row-fence", "-1")

@@ -318,3 +318,61 @@ def test_round3_emission_knobs_and_tuner_dimension(tmp_path):
     # pinned kernels: the register rule is the generator's named state, not round 2's fitted model
     assert t.registerFilter(["--3d", "--dtype", "fp32", "--step", "3", "--order", "rows", "--pack", "0", "--prefetch", "--prefetch-depth", "1", "--bx", "64", "--by", "8", "--block-merge-y", "2", c4])
     assert not t.registerFilter(["--3d", "--dtype", "fp32", "--step", "3", "--order", "rows", "--bx", "32", "--by", "16", "--block-merge-y", "8", c4])
+
+
+def test_output_array_placement_is_published_and_laid_out():
+    """--out-skew (round 3): launch time of a z-streaming kernel depends on (out - in) mod 64 MiB, so the generator publishes a
+    recommended position of the output array (kernel info), the emitted program carves both arrays out of one allocation, and the
+    C ABI / the binding compute the same layout.  Nothing of the kernel text depends on it."""
+    import ctypes
+    import json
+    import re
+    cfg = os.path.join(ROOT, "benchmarks", "configs")
+
+    def gen(args):
+        rc, msg, src = drs.generate(args)
+        assert rc == 0 and src, msg
+        return json.loads(re.search(r'return "(\{.*\})";', src).group(1).replace('\\"', '"')), src
+
+    c4 = os.path.join(cfg, "c4_3d7pt_star_1024.stc")
+    head = ["--3d", "--dtype", "fp32", "--step", "2", "--prefetch", "--prefetch-depth", "3", "--bx", "32", "--by", "16", "--block-merge-x", "4", "--block-merge-y", "2", "--sn", "32"]
+    i, src = gen(head + [c4])
+    assert (i["out_skew_bytes"], i["placement_period_bytes"]) == (32 << 20, 64 << 20)     # reads 5 planes (20 MiB) ahead of its writes: 32 MiB is clear of both bad windows
+    assert "hipMalloc (&arena, out_at + nbytes)" in src and "real_t *in = (real_t*)arena, *out = (real_t*)(arena + out_at);" in src
+    assert "const size_t out_at = (nbytes + 67108863UL) / 67108864UL * 67108864UL + 33554432UL;" in src
+    i8, src8 = gen(head + ["--out-skew", "8", c4])
+    assert i8["out_skew_bytes"] == 8 << 20
+    strip = lambda t: re.sub(r"out_skew_bytes[^,]*,|//.*|const size_t out_at.*", "", t)
+    assert strip(src8.split("int main")[0]).split("dr_c4")[1:] == strip(src.split("int main")[0]).split("dr_c4")[1:]      # same kernels
+    assert gen(head + ["--out-skew", "72", c4])[0]["out_skew_bytes"] == 8 << 20           # taken modulo the period
+    # small planes (512^3: 1 MiB) and 2D kernels are flat: no skew
+    assert gen(["--3d", "--dtype", "fp32", "--step", "2", "--prefetch", os.path.join(cfg, "c3_3d7pt_star_512.stc")])[0]["out_skew_bytes"] == 0
+    assert gen(["--dtype", "fp32", os.path.join(cfg, "c2_2d5pt_star_8192.stc")])[0]["out_skew_bytes"] == 0
+    # layout arithmetic: binding == C ABI
+    k = drs.Kernel(head + ["--cc-opt", "-fno-slp-vectorize", "--xcd-remap", "2", c4])
+    arena, off = k.pair_layout()
+    assert off == (4 << 30) + (32 << 20) and arena == off + (4 << 30) and k.pair_layout(skew=0) == (8 << 30, 4 << 30)
+    a, b = ctypes.c_size_t(), ctypes.c_size_t()
+    fn = drs.lib().drs_kernel_pair_layout
+    fn.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_size_t), ctypes.POINTER(ctypes.c_size_t)]
+    assert fn(k.h, ctypes.byref(a), ctypes.byref(b)) == 0 and (a.value, b.value) == (arena, off)
+
+
+def test_coefficient_register_emission():
+    """--coef sgpr|vgpr: the distinct coefficient values are named scalar / vector constants made opaque by an empty asm, the FMAs
+    refer to them, and the gold kernel is untouched."""
+    stc = os.path.join(ROOT, "tests", "stc", "smoke3.stc")
+    base = ["--3d", "--dtype", "fp32", "--step", "3", "--prefetch", "--prefetch-depth", "1", "--bx", "32", "--by", "8", "--block-merge-y", "2", "--order", "rows", "--pack", "0"]
+    rc, _, lit = drs.generate(base + [stc])
+    rc1, _, sg = drs.generate(base + ["--coef", "sgpr", stc])
+    rc2, _, vg = drs.generate(base + ["--coef", "vgpr", stc])
+    assert rc == rc1 == rc2 == 0
+    assert "DRS_SREG" not in lit and "kc0" not in lit
+    assert 'asm volatile("" : "+s"(x))' in sg and 'asm volatile("" : "+v"(x))' in vg
+    for t in (sg, vg):
+        assert "real_t kc0 = (real_t)(" in t and "DRS_SREG(kc0);" in t and "__builtin_fmaf(kc" in t and "__builtin_fmaf((real_t)(" not in t.split("// naive reference kernel")[0]
+    gold = lambda src: src[src.index("// naive reference kernel"):src.index("// ---- launch entry points")]
+    assert gold(lit) == gold(sg) == gold(vg)
+    assert drs.generate(base + ["--coef", "mmx", stc])[0] == 255
+    # fp64 keeps its literals (the compiler holds them in scalar pairs already)
+    assert "kc0" not in drs.generate(["--3d", "--dtype", "fp64", "--step", "2", "--order", "rows", "--coef", "sgpr", stc])[2]

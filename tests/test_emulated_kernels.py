@@ -68,6 +68,10 @@ VARIANTS = [
     ("2d25_tile_rows", 2, "BOX25", (1, 61, 268), ["--dtype", "fp32", "--order", "rows"]),
     ("2d25_stream_rows_s2", 2, "BOX25", (1, 61, 268), ["--dtype", "fp32", "--streaming", "--sn", "9", "--step", "2", "--prefetch", "--order", "rows"]),
     ("3d_s2_rows_lds_rim", 3, "STAR3", (17, 21, 300), ["--3d", "--dtype", "fp32", "--sn", "6", "--step", "2", "--xrim", "lds", "--order", "rows"]),
+    # round 3: coefficients in scalar / vector registers instead of FMA literals (--coef; the values are the same, DRS_SREG is empty here)
+    ("3d_s3_rows_coef_sgpr", 3, "STAR3", (19, 23, 260), ["--3d", "--dtype", "fp32", "--sn", "8", "--step", "3", "--prefetch", "--order", "rows", "--pack", "0", "--coef", "sgpr", "--bx", "32", "--by", "4", "--block-merge-y", "2"]),
+    ("3d_s2_taps_coef_vgpr", 3, "STAR3", (17, 21, 300), ["--3d", "--dtype", "fp32", "--sn", "6", "--step", "2", "--prefetch", "--coef", "vgpr"]),
+    ("2d25_tile_rows_packed_coef_sgpr", 2, "BOX25", (1, 61, 268), ["--dtype", "fp32", "--order", "rows", "--coef", "sgpr"]),
     ("3d_s2_rows_two_points_per_lane", 3, "STAR3", (17, 21, 300), ["--3d", "--dtype", "fp32", "--sn", "6", "--step", "2", "--order", "rows", "--bx", "16", "--block-merge-x", "2", "--by", "4", "--block-merge-y", "3"]),
     ("3d_s2_taps_pinned", 3, "STAR3", (17, 21, 300), ["--3d", "--dtype", "fp32", "--sn", "6", "--step", "2", "--prefetch", "--pin", "1"]),
     # round 3: wave specialisation -- loader wavefronts request planes by LDS-DMA into a ring, consumers never load (the fibers' barrier counts
