@@ -712,6 +712,17 @@ def main(argv=None):
                                 rehearse_world=pworld if rehearse else 0, cache_dir=os.path.join(ROOT, "drstencil_amd", "_kcache"))
         else:
             run = (SelfNeighbourRun if rehearse else SlabRun)(torch, dist, (L, M, N) if w["ndim"] == 3 else (M, N), H, step, iters, prank, pworld, sweep, dev, tdt, every=args.exchange_every)
+        slab_placement = None
+        if args.placement == "measured" and w["ndim"] == 3:
+            # where this rank's output slab sits relative to its input slab, measured with LOCAL launches of the run's longest-lived kernel
+            # (no exchange, nothing collective; DESIGN.md section 3 "Placement of the two arrays")
+            try:
+                from drstencil_amd.multigpu import calibrate_slab_placement
+                p_ = run.plan
+                kcal = sweep.kernel(p_.Lloc, alone=True) if (p_.every == 2 and sweep.alone_opts is not None) else sweep.kernel(max(p_.views()))
+                slab_placement = calibrate_slab_placement(torch, run, kcal)
+            except Exception as e:       # a kernel that is not in the cache, a CPU run: the arrays stay where slab_pair put them
+                slab_placement = {"skipped": repr(e)}
         g = torch.Generator(device=dev).manual_seed(1 + prank)
         run.A.copy_(torch.rand(run.A.shape, dtype=tdt, device=dev, generator=g))
         torch.cuda.synchronize()     # the run's streams are not the one that filled A
@@ -785,6 +796,8 @@ def main(argv=None):
         }
         if pworld == 1:
             out["config"]["placement"] = placement
+        elif slab_placement is not None:
+            out["config"]["placement"] = dict(slab_placement, mode="measured, rank %d" % prank)
         if pworld > 1:
             out["rank_ms_per_step"] = rank_ms_per_step
             if n1_value:

@@ -279,9 +279,48 @@ def slab_pair(torch, shape, dtype, device, skew=None):
     if skew is None:
         env = os.environ.get("DRS_SLAB_SKEW_MIB")
         skew = (int(env) << 20) if env else ((32 << 20) if plane >= (2 << 20) else 0)
-    off = -(-nb // PLACEMENT_PERIOD) * PLACEMENT_PERIOD + skew % PLACEMENT_PERIOD
-    arena = torch.zeros(off + nb, dtype=torch.uint8, device=device)
+    off0 = -(-nb // PLACEMENT_PERIOD) * PLACEMENT_PERIOD
+    arena = torch.zeros(off0 + PLACEMENT_PERIOD + nb, dtype=torch.uint8, device=device)      # one period of slack: the output can be moved (place_slab_output)
+    off = off0 + skew % PLACEMENT_PERIOD
     return arena[:nb].view(dtype).view(shape), arena[off:off + nb].view(dtype).view(shape), arena
+
+
+def place_slab_output(arena, like, skew):
+    """The output array of a slab_pair arena at `skew` bytes (mod 64 MiB) past the period boundary behind the input; `like` = the input view."""
+    nb = like.numel() * like.element_size()
+    off = -(-nb // PLACEMENT_PERIOD) * PLACEMENT_PERIOD + skew % PLACEMENT_PERIOD
+    return arena[off:off + nb].view(like.dtype).view(like.shape)
+
+
+def calibrate_slab_placement(torch, run, kernel, positions=(0, 16 << 20, 32 << 20, 48 << 20), launches=6):
+    """Measure where this rank's output slab should sit (LOCAL launches only, no exchange: every rank decides for itself, nothing
+    collective).  `kernel` sweeps the first kernel.info["L"] planes of the slab -- the whole-slab kernel of an every = 2 run (one
+    stream block per tile: a single z front, 193 us in the good half of the period and up to 216 in the bad one on a 136-plane slab,
+    profiles/r03_probe_skew_slab.log) or the interior view's.  The phase of the pattern differs from allocation to allocation, so a
+    fixed skew cannot be right everywhere.  Moves run.B (contents zero afterwards, like run.A's are the caller's to fill); returns the table."""
+    if run._arena is None:
+        return None
+    st = torch.cuda.current_stream(run.device)
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+    a = run.A.data_ptr()
+    table = []
+    for sk in positions:
+        b = place_slab_output(run._arena, run.A, sk).data_ptr()
+        kernel.launch(a, b, st.cuda_stream); kernel.launch(b, a, st.cuda_stream)
+        ev[0].record(st)
+        for _ in range(launches):
+            kernel.launch(a, b, st.cuda_stream)
+        ev[1].record(st)
+        for _ in range(launches):
+            kernel.launch(b, a, st.cuda_stream)
+        ev[2].record(st)
+        torch.cuda.synchronize(run.device)
+        table.append((sk, ev[0].elapsed_time(ev[1]) / launches, ev[1].elapsed_time(ev[2]) / launches))
+    best = min(table, key=lambda r: r[1] + r[2])
+    run.B = place_slab_output(run._arena, run.A, best[0])
+    run.A.zero_(); run.B.zero_()
+    run.placement = {"out_minus_in_mod_period_bytes": best[0], "measured_us_fwd_bwd_by_skew_MiB": {str(sk >> 20): [round(1e3 * f, 1), round(1e3 * b, 1)] for sk, f, b in table}}
+    return run.placement
 
 class SlabRun:
     """One rank of a z-slab decomposed run.
