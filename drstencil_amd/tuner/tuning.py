@@ -320,6 +320,10 @@ def measure(kern, torch, A, B, iterations, warmup=10):
     its tolerance horizon (drs_kernel_run refuses more): several short timed loops instead of one long one."""
     hz = kern.info.get("tolerance_horizon_iterations", -1)
     stream = torch.cuda.current_stream().cuda_stream
+    # finite data in every timed loop: with coefficients that sum to 1.5 an array started from U[0, 1) overflows after ~218 time steps, and
+    # the VALU-dense fused kernels run 15-20 % faster on inf / NaN operands (clocks) -- DESIGN.md section 3
+    A.uniform_()
+    B.zero_()
     if kern.info.get("arithmetic") == "reassociated" and not kern.info.get("temporal_forced") and 0 < hz < iterations:
         n = ms = 0
         for rep in range(-(-iterations // hz)):

@@ -136,6 +136,10 @@ def main():
                       k.launch(pair[0].data_ptr(), pair[1].data_ptr()); k.launch(pair[1].data_ptr(), pair[0].data_ptr())
                   torch.cuda.synchronize()
           A, B = bufs[key][:2]
+          # finite data in every timed loop: the test stencils' coefficients sum to more than 1 (star3: 1.5), an array started from U[0, 1)
+          # is all inf after ~218 time steps, and on inf / NaN operands the VALU-dense kernels run 15-20 % FASTER (clocks; probe_cold2.py)
+          if not os.environ.get("EXPLORE_NO_RESEED"):
+              A.uniform_(); B.zero_()
           if name.startswith("gold"):
               for _ in range(2):
                   k.launch_gold(A.data_ptr(), B.data_ptr())
@@ -148,7 +152,14 @@ def main():
               torch.cuda.synchronize()
               n, ms = 4, e0.elapsed_time(e1)
           else:
-              n, ms = k.run_timed(A.data_ptr(), B.data_ptr(), iterations=8 * k.info["step"], warmup=4, stream=torch.cuda.current_stream().cuda_stream)
+              hz = k.info.get("tolerance_horizon_iterations", -1)
+              if k.info.get("arithmetic") == "reassociated" and not k.info.get("temporal_forced") and 0 < hz < 8 * k.info["step"]:
+                  n, ms = 0, 0.0        # a temporal pipeline runs up to its tolerance horizon only: several short loops
+                  for rep in range(4):
+                      n_, ms_ = k.run_timed(A.data_ptr(), B.data_ptr(), iterations=hz, warmup=4 if rep == 0 else 0, stream=torch.cuda.current_stream().cuda_stream)
+                      n, ms = n + n_, ms + ms_
+              else:
+                  n, ms = k.run_timed(A.data_ptr(), B.data_ptr(), iterations=8 * k.info["step"], warmup=4, stream=torch.cuda.current_stream().cuda_stream)
           dur = ms / n
           gbs = k.bytes_per_launch() / dur / 1e6
           gst = k.updates_per_launch() / dur / 1e6
