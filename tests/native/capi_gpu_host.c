@@ -19,7 +19,13 @@ int main(int argc, char **argv) {
     float *h = (float *)malloc(nbytes), *out = (float *)malloc(nbytes), *ref = (float *)malloc(nbytes);
     drs_fill_random_f32(h, n, 1);
     void *a, *b, *ga, *gb;
-    if (hipMalloc(&a, nbytes) || hipMalloc(&b, nbytes) || hipMalloc(&ga, nbytes) || hipMalloc(&gb, nbytes)) { printf("hipMalloc failed\n"); return 1; }
+    /* the optimised kernel's pair in ONE allocation laid out as the kernel recommends (drs_kernel_pair_layout: launch time depends on
+     * (out - in) mod 64 MiB on MI355X); the gold pair as two plain allocations like the reference's host code */
+    size_t arena_bytes = 0, out_at = 0;
+    char *arena;
+    if (drs_kernel_pair_layout(k, &arena_bytes, &out_at) != 0 || out_at < nbytes || arena_bytes != out_at + nbytes || out_at % 4096) { printf("pair layout failed\n"); return 1; }
+    if (hipMalloc((void **)&arena, arena_bytes) || hipMalloc(&ga, nbytes) || hipMalloc(&gb, nbytes)) { printf("hipMalloc failed\n"); return 1; }
+    a = arena; b = arena + out_at;
     hipMemcpy(a, h, nbytes, hipMemcpyHostToDevice); hipMemset(b, 0, nbytes);
     hipMemcpy(ga, h, nbytes, hipMemcpyHostToDevice); hipMemset(gb, 0, nbytes);
     float ms = 0.f;
