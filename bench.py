@@ -147,7 +147,7 @@ FUSED3 = {
               ["--3d", "--dtype", "fp64", "--step", "3", "--prefetch", "--prefetch-depth", "1", "--order", "rows", "--bx", "128", "--by", "4", "--block-merge-x", "2", "--block-merge-y", "2", "--sn", "32", "--xcd-remap", "2"]],
     "c3": [_S3 + ["--bx", "64", "--by", "8", "--block-merge-y", "2", "--sn", "64", "--xcd-remap", "1"],
            _S3 + ["--bx", "32", "--by", "16", "--block-merge-y", "2", "--sn", "32", "--xcd-remap", "2"],
-           _S3 + ["--bx", "16", "--by", "16", "--block-merge-y", "2", "--sn", "64", "--xcd-remap", "2"]],
+           _S3 + ["--xrim", "lds", "--bx", "64", "--by", "8", "--block-merge-y", "2", "--sn", "64", "--xcd-remap", "2"]],      # the fastest on finite data (r03_exp_r3n.log)
 }
 # N > 1 (z slabs of C4): the same fused kernel; slabs of 256 planes or fewer get 16-plane stream blocks.  One stream block
 # per tile (256 tiles = one workgroup per CU) is the fastest way to sweep a slab ALONE (128-plane view 0.186 ms vs 0.199,

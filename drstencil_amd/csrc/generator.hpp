@@ -100,6 +100,8 @@ MI355X options:
                         takes up to 14 % longer on MI355X (profiles/r03_probe_skew4.log).  Default: chosen from the kernel's read-ahead
                         distance (32 or 0).  The emitted program allocates both arrays in one arena accordingly; callers of the C ABI
                         read the recommendation from the kernel info (out_skew_bytes, placement_period_bytes).  Results never depend on it.
+--zigzag <0|1>          1: a launch whose output array lies below its input array (every second launch of the reference's ping-pong loop)
+                        walks its stream blocks in reverse order and so begins on the planes the previous launch wrote last.
 --coef <lit|sgpr|vgpr>  fp32: coefficients as 32-bit literals of every FMA (lit, default) or held in scalar registers (sgpr: 4-byte
                         instead of 8-byte FMAs -- code size and instruction fetch of the fused multi-step kernels; same results).
 --temporal <0|1|force>  With --step n > 1: run the one-step stencil n times on chip (temporal blocking,
@@ -210,6 +212,7 @@ inline GenResult generate(const std::vector<std::string> &args /* argv[1..] */) 
         else if (a == "--clamp-loads") { if (!int_opt(o.clamp_loads, nullptr)) break; }
         else if (a == "--halo-spread") { if (!int_opt(o.halo_spread, nullptr)) break; }
         else if (a == "--zgroup") { if (!int_opt(o.zgroup, nullptr)) break; }
+        else if (a == "--zigzag") { if (!int_opt(o.zigzag, nullptr)) break; }
         else if (a == "--pair-launch") { if (!int_opt(o.pair_launch, nullptr)) break; }
         else if (a == "--prefetch-auto") { if (!int_opt(o.prefetch_auto, nullptr)) break; }
         else if (a == "--prefetch-depth") { if (!int_opt(o.prefetch_depth, nullptr)) break; }
