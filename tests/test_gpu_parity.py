@@ -295,6 +295,55 @@ def test_drift_shapes_are_fenced(torch_cuda, cid, ndim, stc, opts, unforced):
     assert rel <= 1e-5 and rel <= 2.0 * kf.info["drift_estimate"], (cid, rel, kf.info["drift_estimate"])
 
 
+def test_pair_allocation_with_measured_placement(torch_cuda):
+    """Kernel.alloc_pair (round 3): both arrays as views of one allocation, the output array's position measured on the device; the
+    kernel run on that pair equals the gold kernel run on two plain tensors, bit for bit, and pair_layout agrees with the C ABI."""
+    import drstencil_amd as drs
+    from gpu_cases import stc as stcp
+    torch = torch_cuda
+    k = drs.Kernel(["--3d", "--dtype", "fp32", "--step", "2", "--sn", "32", stcp("t3_star")])       # = SMALL's 3d7_fp32_step2: prebuilt
+    spec = oracle.Spec(stcp("t3_star"), 3, 2)
+    A, B, arena = k.alloc_pair(torch, torch.device("cuda", 0), calibrate=True)
+    period = k.info["placement_period_bytes"]
+    assert tuple(A.shape) == tuple(spec.dims) and A.dtype == torch.float32 and len(k.skew_calibration) == 4
+    assert (B.data_ptr() - A.data_ptr()) % period == k.pair_skew_bytes and B.data_ptr() - A.data_ptr() >= A.numel() * 4
+    A0 = torch.as_tensor(oracle.fill_random(spec.shape, np.float32)).cuda()
+    A.copy_(A0); B.zero_()
+    Ag, Bg = A0.clone(), torch.zeros_like(A0)
+    n = k.run(A.data_ptr(), B.data_ptr(), iterations=8)
+    ng = k.run(Ag.data_ptr(), Bg.data_ptr(), iterations=8, gold=True)
+    torch.cuda.synchronize()
+    assert n == ng == 4 and torch.equal(A, Ag) and torch.equal(B, Bg)
+    A2, B2, _ = k.alloc_pair(torch, torch.device("cuda", 0))                 # the kernel's own recommendation (small planes: no skew)
+    assert B2.data_ptr() - A2.data_ptr() == k.pair_layout()[1]
+
+
+@pytest.mark.parametrize("cid,ndim,stc,opts,unforced", DRIFT, ids=[c[0] for c in DRIFT])
+def test_drift_shapes_are_fenced(torch_cuda, cid, ndim, stc, opts, unforced):
+    """Shapes whose temporal pipelines are beyond 1e-6 at their own iteration counts (dense boxes at step 2-3; gpu_cases.DRIFT):
+    `--temporal 1` must hand back something that keeps the bar -- here the fused kernel, bit-exact -- and the forced pipeline shows
+    the drift the fence is there for: beyond or near the bar, within 10x of it, and within twice the generator's estimate."""
+    import drstencil_amd as drs
+    torch = torch_cuda
+    spec = oracle.Spec(stc, ndim, _step(opts))
+    A0 = oracle.fill_random(spec.shape, np.float32)
+    A_ref, B_ref = A0.copy(), np.zeros_like(A0)
+    oracle.run(spec, A_ref, B_ref, contract=1)
+    if unforced:
+        kern = drs.Kernel(opts + ["--temporal", "1", stc])
+        n, A, B = run_hip(torch, kern, A0, np.zeros_like(A0))
+        if kern.info["arithmetic"] == "gold-order":
+            assert np.array_equal(A, A_ref) and np.array_equal(B, B_ref), cid
+        else:       # the generator claims the bar for this pipeline
+            assert max(oracle.check(spec, A, A_ref)["max_rel"], oracle.check(spec, B, B_ref)["max_rel"]) <= 1e-6, cid
+    kf = drs.Kernel(opts + ["--temporal", "force", stc])
+    assert kf.info["arithmetic"] == "reassociated" and kf.info["temporal_forced"] == 1 and kf.info["drift_estimate"] > 1e-6
+    n, A, B = run_hip(torch, kf, A0, np.zeros_like(A0))
+    rel = max(oracle.check(spec, A, A_ref)["max_rel"], oracle.check(spec, B, B_ref)["max_rel"])
+    print("drift %s: forced pipeline %.3g, estimate %.3g" % (cid, rel, kf.info["drift_estimate"]))
+    assert rel <= 1e-5 and rel <= 2.0 * kf.info["drift_estimate"], (cid, rel, kf.info["drift_estimate"])
+
+
 def test_dpp_wave_shift_semantics(torch_cuda):
     """--xrim dpp relies on wave_shr:1 / wave_shl:1 moving data by one lane across the whole
     64-lane wavefront on gfx950: a dpp kernel and an lds kernel must agree bit for bit."""
@@ -691,6 +740,14 @@ def test_rccl_exchange_choreography_on_one_gpu(torch_cuda, tmp_path, every):
         res = []
         for cls in (SelfNeighbourRun, SelfCopy):
             run = cls(torch, dist, (L, M, N), H, 2, 24, 1, 3, sweep, dev, torch.float32, every=every)   # middle rank of 3
+            if cls is SelfNeighbourRun:
+                # bench.py's placement step (round 3): the output slab is moved to the measured position inside the arena -- local
+                # launches only -- before the data goes in; the result below must not notice
+                from drstencil_amd.multigpu import PLACEMENT_PERIOD, calibrate_slab_placement
+                placed = calibrate_slab_placement(torch, run, sweep.kernel(max(run.plan.views())))
+                assert placed and len(placed["measured_us_fwd_bwd_by_skew_MiB"]) == 4
+                assert (run.B.data_ptr() - run.A.data_ptr()) % PLACEMENT_PERIOD == placed["out_minus_in_mod_period_bytes"]
+                assert int(torch.count_nonzero(run.A)) == 0 and int(torch.count_nonzero(run.B)) == 0
             run.load_global(lambda lo, hi: A0[lo:hi])
             n = run.run()
             torch.cuda.synchronize()
