@@ -558,6 +558,9 @@ def main(argv=None):
         for r in (range(pworld) if args.prebuild_only else (prank,)):
             for ev in ((1, 2) if auto_every else (args.exchange_every,)):      # both modes' kernels: built (cache hits) before HIP is up
                 sweep.prebuild(SlabPlan(L if w["ndim"] == 3 else M, H, pworld, r, ev))
+                if os.environ.get("DRS_EXP_SLAB") == "folded":        # timing experiment (multigpu.SlabRun.launch): boundary + interior as one view
+                    sp_ = SlabPlan(L if w["ndim"] == 3 else M, H, pworld, r, ev)
+                    sweep.kernel((sp_.bot[1] if sp_.bot else sp_.interior[1]) - (sp_.top[0] if sp_.top else sp_.interior[0]))
             if not args.no_verify and not rehearse:       # the wider no-exchange slab of verify_slab_run
                 vlo, vhi = slab_verify_view(L if w["ndim"] == 3 else M, H, spec.launches, pworld, r)
                 sweep.kernel(vhi - vlo)

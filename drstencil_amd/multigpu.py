@@ -377,7 +377,21 @@ class SlabRun:
         a, b = p.interior
         if self.gpu and self.world > 1:
             sh = self.main.cuda_stream
-            if p.pair_view() and hasattr(self.sweep, "pair"):
+            exp = os.environ.get("DRS_EXP_SLAB", "")      # timing experiments (wrong results), DESIGN.md section 4: what each piece of an exchanging launch costs
+            if exp == "folded":
+                # the best a boundary-inside-the-interior-launch scheme could do: ONE launch over boundary + interior, the exchange started at once
+                self.ev_b.record(self.main)
+                self.sweep(src[p.top[0] if p.top else a:(p.bot[1] if p.bot else b)], dst[p.top[0] if p.top else a:(p.bot[1] if p.bot else b)], sh)
+                with self.torch.cuda.stream(self.side):
+                    self.side.wait_event(self.ev_b)
+                    self._exchange(dst)
+                    self.ev_c.record(self.side)
+                self.main.wait_event(self.ev_c)
+                self.launch_count += 1
+                return
+            if exp == "noboundary":
+                pass
+            elif p.pair_view() and hasattr(self.sweep, "pair"):
                 self.sweep.pair(src[p.top[0]:p.top[1]], dst[p.top[0]:p.top[1]], src[p.bot[0]:p.bot[1]], dst[p.bot[0]:p.bot[1]], sh)
             else:
                 for v in (p.top, p.bot):
@@ -386,6 +400,9 @@ class SlabRun:
             self.ev_b.record(self.main)
             if b - a > 2 * H:
                 self.sweep(src[a:b], dst[a:b], sh)
+            if exp == "noexchange":
+                self.launch_count += 1
+                return
             with self.torch.cuda.stream(self.side):
                 self.side.wait_event(self.ev_b)
                 self._exchange(dst)
