@@ -363,7 +363,8 @@ def verify_slab_run(torch, dist, run, sweep, dims, H, launches, iters, rank, wor
     sync()
     okA = torch.equal(run.owned(run.A), A[p.z0 - lo:p.z1 - lo])
     okB = torch.equal(run.owned(run.B), B[p.z0 - lo:p.z1 - lo])
-    flag = torch.tensor([1 if (okA and okB) else 0], dtype=torch.int32, device=dev)
+    from drstencil_amd.multigpu import coll_device
+    flag = torch.tensor([1 if (okA and okB) else 0], dtype=torch.int32, device=coll_device(torch, dist, dev))
     dist.all_reduce(flag, op=dist.ReduceOp.MIN)
     return bool(int(flag[0])), {"decomposed_vs_single_domain": {"ok": bool(int(flag[0])), "this_rank_ok": bool(okA and okB), "launches": n, "bit_exact_required": True,
                                                                 "how": "own planes of the exchanged run == plain launches on [z0 - %d, z1 + %d) of the same seeded global grid" % (launches * H, launches * H)}}
@@ -571,15 +572,31 @@ def main(argv=None):
     import torch
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the product path has no CPU fallback)")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # DRS_BENCH_BACKEND=gloo DRS_BENCH_ONE_GPU=1: a rehearsal of the real multi-process N > 1 path where only one GPU exists -- every rank
+    # process computes on cuda:0 and the halo planes travel through a gloo group staged in host memory (multigpu.batch_p2p).  Everything
+    # but the RCCL transport is the code of a real run: the launcher, the ranks' own kernels (first, middle, last), the exchange
+    # choreography, the self-check.  The line says so, and its value is meaningless as a rate (<= 6 rank processes per GPU on the pool).
+    backend = os.environ.get("DRS_BENCH_BACKEND", "nccl")
+    one_gpu = bool(os.environ.get("DRS_BENCH_ONE_GPU"))
+    if (backend != "nccl" or one_gpu) and args.slab_runtime == "native":
+        raise SystemExit("bench.py: the native slab runtime calls RCCL directly (no gloo / one-GPU rehearsal)")
+    gpu_index = 0 if one_gpu else local_rank
+    torch.cuda.set_device(gpu_index)
+    dev = torch.device("cuda", gpu_index)
     dist = None
     if pworld > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29541")
         from drstencil_amd.multigpu import nccl_options
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev, pg_options=nccl_options(dist))
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev, pg_options=nccl_options(dist))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
+    cdev = dev         # where the few-element tensors of the collectives below live (the CPU under gloo)
+    if dist is not None:
+        from drstencil_amd.multigpu import coll_device
+        cdev = coll_device(torch, dist, dev)
 
     tdt = torch.float32 if w["dtype"] == "fp32" else torch.float64
     esz = 4 if w["dtype"] == "fp32" else 8
@@ -704,7 +721,7 @@ def main(argv=None):
         # --gpus N` passes no --n1-value): the single-GPU headline kernel on a scratch copy of the whole grid, same protocol as N = 1
         n1_value = args.n1_value
         if n1_value is None and kern_n1 is not None:
-            n1 = torch.zeros(2, dtype=torch.float64, device=dev)
+            n1 = torch.zeros(2, dtype=torch.float64, device=cdev)
             if rank == 0:
                 shape1 = (L, M, N) if w["ndim"] == 3 else (M, N)
                 A1 = torch.rand(shape1, dtype=tdt, device=dev)
@@ -777,11 +794,11 @@ def main(argv=None):
         torch.cuda.synchronize()
         el = time.perf_counter() - t0
         ev_ms = e0.elapsed_time(e1)
-        mine = torch.tensor([el * 1e3 / max(args.steps, 1)], dtype=torch.float64, device=dev)
+        mine = torch.tensor([el * 1e3 / max(args.steps, 1)], dtype=torch.float64, device=cdev)
         per_rank = [torch.zeros_like(mine) for _ in range(world)]
         dist.all_gather(per_rank, mine)
         rank_ms_per_step = [float(x[0]) for x in per_rank]
-        t = torch.tensor([el, ev_ms], dtype=torch.float64, device=dev)
+        t = torch.tensor([el, ev_ms], dtype=torch.float64, device=cdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         el, ev_ms = float(t[0]), float(t[1])
         kinfo = sweep.kernel(run.plan.interior[1] - run.plan.interior[0]).info
@@ -800,6 +817,9 @@ def main(argv=None):
         if rehearse:    # one rank's share of the work only: the other ranks do not exist
             updates /= pworld
             parallelism = "REHEARSAL on one GPU of rank %d of %d (self-neighbour exchange through RCCL): %s" % (prank, pworld, parallelism)
+        if pworld > 1 and (backend != "nccl" or one_gpu):
+            parallelism = "REHEARSAL: %d rank processes on %s, halo planes through a %s group%s -- not a rate: %s" % (
+                pworld, "ONE GPU" if one_gpu else "their GPUs", backend, " staged in host memory" if backend == "gloo" else "", parallelism)
         value = updates / el / 1e9
         # roofline of the dominant kernel dr_<name>: algorithmic bytes per launch / average
         # launch duration from the HIP events around the timed launches

@@ -148,11 +148,10 @@ def measure_exchange_every(torch, dist, dims, H, rank, world, sweep, device, dty
         def exchange():
             ops = []
             if has_up:
-                ops += [dist.P2POp(dist.isend, bufs[0], up), dist.P2POp(dist.irecv, bufs[1], dn if self_neighbour else up)]
+                ops += [("send", bufs[0], up), ("recv", bufs[1], dn if self_neighbour else up)]
             if has_dn:
-                ops += [dist.P2POp(dist.isend, bufs[2], dn), dist.P2POp(dist.irecv, bufs[3], up if self_neighbour else dn)]
-            for w in dist.batch_isend_irecv(ops):
-                w.wait()
+                ops += [("send", bufs[2], dn), ("recv", bufs[3], up if self_neighbour else dn)]
+            batch_p2p(torch, dist, ops)
         return timed(exchange) if (has_up or has_dn) else 0.0
 
     x1, x2 = exchange_us(H), exchange_us(2 * H)
@@ -180,7 +179,7 @@ def measure_exchange_every(torch, dist, dims, H, rank, world, sweep, device, dty
     planes = min(slab_bounds(dims[0], world, r)[1] - slab_bounds(dims[0], world, r)[0] for r in range(world))
     b1 = boundary_us(1)
     b2 = boundary_us(2) if planes >= 8 * H else b1
-    t = torch.tensor([sweep_us, x1, x2, b1, b2], dtype=torch.float64, device=device)
+    t = torch.tensor([sweep_us, x1, x2, b1, b2], dtype=torch.float64, device=coll_device(torch, dist, device))
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     sweep_us, x1, x2, b1, b2 = (float(v) for v in t)
     # time of one ping-pong pair (two launches) in each mode: boundary launch, then the interior sweep beside the exchange
@@ -215,6 +214,32 @@ def nccl_options(dist):
     o.is_high_priority_stream = os.environ.get("DRS_RCCL_HIGH_PRIORITY", "1") != "0"   # 0: experiments only
     return o
 
+
+
+def coll_device(torch, dist, device):
+    """Where the few-element tensors of this package's collectives live: on the device with RCCL; on the CPU when the process group
+    is gloo -- the CPU tests, and rehearsals of the N > 1 path with several rank processes sharing ONE GPU (DRS_BENCH_BACKEND=gloo),
+    where gloo has no GPU all_gather / send / recv."""
+    return torch.device("cpu") if (dist is not None and getattr(dist, "get_backend", lambda: "")() == "gloo") else device
+
+
+def batch_p2p(torch, dist, ops):
+    """ops = [("send" | "recv", tensor, peer), ...] as ONE batch (RCCL: a single ncclGroupStart / ncclGroupEnd).  With a gloo group and
+    device tensors the planes are staged through host memory (rehearsal only: correct, not fast); the copies run on the current stream
+    and block the host, so the caller's stream / event choreography still orders them."""
+    if not ops:
+        return
+    staged = getattr(dist, "get_backend", lambda: "")() == "gloo" and any(t.is_cuda for _, t, _ in ops)      # (the tests' in-process stand-in has no backend)
+    if not staged:
+        for w in dist.batch_isend_irecv([dist.P2POp(dist.isend if k == "send" else dist.irecv, t, peer) for k, t, peer in ops]):
+            w.wait()
+        return
+    host = [(k, t, peer, t.cpu() if k == "send" else torch.empty(t.shape, dtype=t.dtype)) for k, t, peer in ops]
+    for w in dist.batch_isend_irecv([dist.P2POp(dist.isend if k == "send" else dist.irecv, h, peer) for k, _, peer, h in host]):
+        w.wait()
+    for k, t, _, h in host:
+        if k == "recv":
+            t.copy_(h)
 
 class HipSweep:
     """Product sweep backend: generated HIP kernel for a view of Lv planes."""
@@ -361,15 +386,12 @@ class SlabRun:
         p, dist = self.plan, self.dist
         ops = []
         if p.has_up:
-            ops.append(dist.P2POp(dist.isend, dst[p.send_up[0]:p.send_up[1]], self.rank - 1))
-            ops.append(dist.P2POp(dist.irecv, dst[p.recv_up[0]:p.recv_up[1]], self.rank - 1))
+            ops.append(("send", dst[p.send_up[0]:p.send_up[1]], self.rank - 1))
+            ops.append(("recv", dst[p.recv_up[0]:p.recv_up[1]], self.rank - 1))
         if p.has_dn:
-            ops.append(dist.P2POp(dist.isend, dst[p.send_dn[0]:p.send_dn[1]], self.rank + 1))
-            ops.append(dist.P2POp(dist.irecv, dst[p.recv_dn[0]:p.recv_dn[1]], self.rank + 1))
-        if not ops:
-            return
-        for w in dist.batch_isend_irecv(ops):
-            w.wait()
+            ops.append(("send", dst[p.send_dn[0]:p.send_dn[1]], self.rank + 1))
+            ops.append(("recv", dst[p.recv_dn[0]:p.recv_dn[1]], self.rank + 1))
+        batch_p2p(self.torch, dist, ops)
 
     def launch(self, src, dst):
         """One launch src -> dst with halo exchange of dst."""

@@ -185,6 +185,22 @@ def _run_bench_rehearsal():
         f.write(stdout)
     with open(os.path.join(out, "stderr.txt"), "w") as f:
         f.write(text)
+    # ... and the REAL multi-process form, as the driver launches it: two rank processes under torch.distributed.run, both computing on this
+    # one GPU, the halo planes through a gloo group staged in host memory (DRS_BENCH_BACKEND=gloo DRS_BENCH_ONE_GPU=1): the launcher
+    # environment, a first and a last rank with their own kernels, the exchange choreography and the decomposed-vs-single-domain check
+    # across real processes -- everything of an N = 2 run but the RCCL transport
+    env2 = dict(os.environ, DRS_BENCH_BACKEND="gloo", DRS_BENCH_ONE_GPU="1")
+    try:
+        r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29631",
+                            os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"],
+                           env=env2, capture_output=True, text=True, timeout=420, cwd=ROOT)
+        stdout, text = r.stdout, "[rc=%d]\n%s" % (r.returncode, r.stderr[-1500:])
+    except Exception as e:
+        stdout, text = "", "[exception] %r" % (e,)
+    with open(os.path.join(out, "two_ranks_stdout.txt"), "w") as f:
+        f.write(stdout)
+    with open(os.path.join(out, "two_ranks_stderr.txt"), "w") as f:
+        f.write(text)
 
 
 def pytest_sessionstart(session):

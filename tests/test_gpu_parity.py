@@ -478,6 +478,22 @@ def test_bench_stdout_is_one_json_line_with_rccl_up():
     assert rec["roofline"]["bound"] == "hbm" and rec["config"]["exchange_calibration"]["chosen_every"] in (1, 2)
 
 
+def test_two_rank_processes_under_the_launcher_verify_themselves():
+    """`python -m torch.distributed.run --nproc-per-node 2 bench.py --gpus 2` -- the driver's own form -- rehearsed at session start with
+    both rank processes on this one GPU and a gloo group staged in host memory instead of RCCL (conftest._run_bench_rehearsal): rank 0's
+    stdout is one JSON line for 2 ranks whose self-check (every rank's own planes of the exchanged run == plain launches on a wider slab
+    of the same seeded global grid, AND-ed over the ranks) is green, with a first and a last rank as separate processes."""
+    d = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "drstencil_amd", "_kcache", "bench_rehearsal")
+    out, err = open(os.path.join(d, "two_ranks_stdout.txt")).read(), open(os.path.join(d, "two_ranks_stderr.txt")).read()
+    assert err.startswith("[rc=0]"), err[-1500:]
+    lines = out.splitlines()
+    assert len(lines) == 1, out[:600]
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["verified"] is True and len(rec["rank_ms_per_step"]) == 2
+    assert rec["verification"]["decomposed_vs_single_domain"]["ok"] is True and rec["verification"]["decomposed_vs_single_domain"]["bit_exact_required"] is True
+    assert "REHEARSAL: 2 rank processes on ONE GPU" in rec["config"]["parallelism"] and rec["efficiency_vs_n1"] > 0
+
+
 def test_c_host_through_the_abi():
     """A plain-C host (tests/native/capi_gpu_host.c = the INTEGRATION.md example) built with gcc, run at session start:
     drs_kernel_build, hipMalloc'ed buffers, drs_kernel_run_timed, the gold kernel through drs_kernel_run, drs_check_error --
@@ -536,6 +552,9 @@ class _Hub:
 
 class _FakeDist:
     isend, irecv = "isend", "irecv"
+
+    def get_backend(self):
+        return "in-process"
 
     class P2POp:
         def __init__(self, op, tensor, peer):
