@@ -95,6 +95,10 @@ MI355X options:
                         loop is unrolled by lcm(n, LDS slots, prefetch sets): e.g. Range 7 -> 14 plane bodies, --rot-mod 8 -> 8
                         (code size; the instruction cache holds 64 KB).
 --row-fence <mask>      sched_barrier mask between row groups (0 default: nothing crosses; -1: no fence).
+--gpus <N>              N > 1: the emitted program's main() runs the spec slab-decomposed over N GPUs of one node (z slabs in 3D, y slabs in 2D): it
+                        forks one rank process per GPU before any HIP call and drives the C ABI's drs_slab_* entry points (RCCL send/recv of the
+                        halo planes, overlapped with the interior sweep).  Link it with -ldrstencil_amd; DRS_SLAB_REHEARSE=r/N runs rank r alone
+                        on one GPU.  The kernels in the file (and its use as a plugin) are unchanged.
 --out-skew <MiB>        Placement of the output array relative to the input array: (out - in) mod 64 MiB.  A z-streaming kernel reads a few
                         planes ahead of the plane it writes; when its writes land, modulo 64 MiB, 8-16 MiB behind its read front the launch
                         takes up to 14 % longer on MI355X (profiles/r03_probe_skew4.log).  Default: chosen from the kernel's read-ahead
@@ -193,6 +197,7 @@ inline GenResult generate(const std::vector<std::string> &args /* argv[1..] */) 
         else if (a == "--pack") { if (!int_opt(o.pack, nullptr)) break; }
         else if (a == "--row-fence") { if (!int_opt(o.row_fence, nullptr)) break; }
         else if (a == "--out-skew") { if (!int_opt(o.out_skew, nullptr)) break; }
+        else if (a == "--gpus") { if (!int_opt(o.gpus, nullptr)) break; }
         else if (a == "--coef") {
             std::string v;
             if (!str_opt(v)) break;
@@ -272,6 +277,12 @@ inline GenResult generate(const std::vector<std::string> &args /* argv[1..] */) 
     if (!res.plan.note.empty()) res.messages += "drstencil: note: " + res.plan.note + "\n";
     std::string cmdline;
     for (size_t i = 0; i + 1 < args.size(); i++) cmdline += (i ? " " : "") + args[i];
+    for (size_t i = 0; i + 1 < args.size(); i++) {
+        if (args[i] == "-o" || args[i] == "--gpus") { i++; continue; }
+        if (args[i] == "--check" || args[i] == "--gold") continue;
+        o.slab_args.push_back(args[i]);
+    }
+    if (o.gpus < 1 || o.gpus > 64) { res.messages += "Illegal input.\n"; res.exit_code = 255; return res; }
     HipEmitter em(res.plan, o);
     if (!em.config_error().empty()) { res.messages += "Invalid configuration!\n"; res.exit_code = 255; res.plan.error = em.config_error(); return res; }
     if (em.lds_bytes() > 160 * 1024) {   // gfx950: 160 KiB of LDS per workgroup

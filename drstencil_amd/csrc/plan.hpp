@@ -148,6 +148,9 @@ struct GenOptions {
                                  // other use -- and keeps the SOURCE windows of all those planes alive instead of one partial sum (seen in the
                                  // ISA: one mul + 62 FMAs on one register pair right in front of the store, 370 live values for 136 named
                                  // ones, profiles/r03_sinking.md).  The pin makes each update used where it is written.  -1 auto: on with --order rows
+    int gpus = 1;                // --gpus N > 1: the emitted program's main() is an N-GPU host -- launcher and ranks in one (it forks its ranks before any
+                                 // HIP call, one process per GPU) on the C ABI's drs_slab_* entry points (z slabs / y slabs, RCCL send/recv halo exchange)
+    std::vector<std::string> slab_args;   // the generator options of this invocation without -o / --gpus / --check / --gold and without the .stc path
     int out_skew = -1;           // --out-skew <MiB>: where the output array should sit relative to the input array, modulo 64 MiB (see
                                  // HipEmitter::out_skew_bytes; -1: chosen by the generator).  It changes no kernel text: the value is published
                                  // in the info JSON / the banner and honoured by the emitted host program, which owns its allocations

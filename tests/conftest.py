@@ -168,6 +168,23 @@ def _run_c_host(drs):
         f.write(text)
 
 
+def _run_gpus_host():
+    """`drstencil --gpus N`: the emitted N-GPU host generated, compiled and run on this one GPU (scripts/try_gpus_host.sh) before this
+    process touches HIP: a rehearsed middle rank, the forking form (which must give up cleanly: ranks 1..3 have no GPU), a one-rank
+    world with --check, and the 2D y-slab forms."""
+    import subprocess
+    out = os.path.join(ROOT, "drstencil_amd", "_kcache", "gpus_host")
+    os.makedirs(out, exist_ok=True)
+    try:
+        r = subprocess.run(["bash", os.path.join(ROOT, "scripts", "try_gpus_host.sh"), out], capture_output=True, text=True, timeout=600, cwd=ROOT,
+                           env=dict(os.environ, GRAFT_REPO_ROOT=ROOT))
+        text = "[rc=%d]\n%s\n[stderr]\n%s" % (r.returncode, r.stdout, r.stderr[-1500:])
+    except Exception as e:
+        text = "[exception] %r" % (e,)
+    with open(os.path.join(out, "stdout.txt"), "w") as f:
+        f.write(text)
+
+
 def _run_bench_rehearsal():
     """bench.py's N > 1 branch as a child process (rank 1 of 4 on this one GPU, self-neighbour exchange through a real RCCL
     process group), before this process touches HIP: the test reads what arrived on its stdout."""
@@ -220,6 +237,7 @@ def pytest_sessionstart(session):
     _run_tuner_smoke()
     _run_reference_flow(drs)
     _run_c_host(drs)
+    _run_gpus_host()
     _run_bench_rehearsal()
     from gpu_cases import all_build_args, golden_args
     from helpers import golden_cases, load_golden

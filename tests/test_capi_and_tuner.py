@@ -376,3 +376,23 @@ def test_coefficient_register_emission():
     assert drs.generate(base + ["--coef", "mmx", stc])[0] == 255
     # fp64 keeps its literals (the compiler holds them in scalar pairs already)
     assert "kc0" not in drs.generate(["--3d", "--dtype", "fp64", "--step", "2", "--order", "rows", "--coef", "sgpr", stc])[2]
+
+
+def test_gpus_option_emits_an_n_gpu_host():
+    """--gpus N > 1 replaces the emitted program's main() by the N-GPU host (launcher + ranks, drs_slab_* through the C ABI) and leaves every
+    kernel, the gold kernel and the plugin entry points as they are."""
+    stc = os.path.join(ROOT, "tests", "stc", "t3_star.stc")
+    base = ["--3d", "--dtype", "fp32", "--step", "2", "--sn", "16"]
+    rc1, _, one = drs.generate(base + ["--check", "-o", "x.hip", stc])
+    rc4, _, four = drs.generate(base + ["--gpus", "4", "--check", "-o", "x.hip", stc])
+    assert rc1 == rc4 == 0
+    cut = lambda t: t[t.index("#include <hip/hip_runtime.h>"):t.index("#ifndef DRS_PLUGIN\n", t.index("// ---- launch entry points"))]
+    assert cut(one) == cut(four)                                             # same kernels, same plugin API
+    host = four[four.index("#ifndef DRS_PLUGIN\n", four.index("// ---- launch entry points")):]
+    assert "#define DRS_WORLD 4" in host and 'static const char *drs_opts[] = { "--3d", "--dtype", "fp32", "--step", "2", "--sn", "16", NULL };' in host
+    assert '"L 70\\nM 45\\nN 530\\n' in host and "fork ()" in host and "drs_slab_open (" in host and "drs_slab_connect (" in host and "#pragma push_macro(\"L\")" in host
+    assert "#if 1\n    if (!rh) {" in host and "checkError3D (M, N, h_own, h_gold" in host           # --check: own planes vs the gold kernel on a wider slab
+    assert "drs_slab_open" not in one and "#define DRS_WORLD" not in one
+    rc2d, _, two = drs.generate(["--dtype", "fp64", "--gpus", "2", os.path.join(ROOT, "tests", "stc", "t2_star.stc")])
+    assert rc2d == 0 and "const long DIM0 = M;" in two and "const size_t plane = (size_t)N;" in two and "#if 0\n    if (!rh) {" in two
+    assert drs.generate(base + ["--gpus", "0", stc])[0] == 255 and drs.generate(base + ["--gpus", "65", stc])[0] == 255

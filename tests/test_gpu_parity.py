@@ -494,6 +494,21 @@ def test_two_rank_processes_under_the_launcher_verify_themselves():
     assert "REHEARSAL: 2 rank processes on ONE GPU" in rec["config"]["parallelism"] and rec["efficiency_vs_n1"] > 0
 
 
+def test_emitted_n_gpu_host():
+    """`drstencil --gpus N` (round 3): the emitted program whose main() is launcher and ranks in one, on the C ABI's drs_slab_* entry
+    points -- run at session start by scripts/try_gpus_host.sh on this one GPU."""
+    d = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "drstencil_amd", "_kcache", "gpus_host")
+    text = open(os.path.join(d, "stdout.txt")).read()
+    assert text.startswith("[rc=0]"), text[-2000:]
+    part = lambda tag: text.split("== (%s)" % tag, 1)[1].split("\n== (", 1)[0]
+    a, b, b2, c2, c = part("a"), part("b"), part("b2"), part("c2"), part("c")
+    assert "rc=0" in a and "[rank 1 of 4] planes [15, 37) of 70, owns [17, 35)" in a and "(REHEARSAL of one rank)" in a and "[Perf] achieved" in a
+    assert "rc=1" in b and "not every rank has a GPU" in b and "[Perf]" not in b and b.count("no GPU") == 3         # ranks 1..3 of 4 on a one-GPU box
+    for one_rank in (b2, c2):                      # a one-rank world through the same code: the slab run == the gold kernel on the whole grid
+        assert "rc=0" in one_rank and "[Test] RMS Error : 0.000000e+00" in one_rank and "on 1 GPU(s)," in one_rank
+    assert "rc=0" in c and "[rank 1 of 3] planes [99, 201) of 301, owns [100, 200)" in c
+
+
 def test_c_host_through_the_abi():
     """A plain-C host (tests/native/capi_gpu_host.c = the INTEGRATION.md example) built with gcc, run at session start:
     drs_kernel_build, hipMalloc'ed buffers, drs_kernel_run_timed, the gold kernel through drs_kernel_run, drs_check_error --
