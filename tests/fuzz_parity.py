@@ -44,6 +44,17 @@ def round3_knobs(rnd, cl):
         cl += ["--loader-waves", str(rnd.choice([1, 2, 3]))]
         if "--prefetch-depth" not in cl:
             cl += ["--prefetch-depth", str(rnd.choice([1, 2, 3, 4]))]
+    # second half of round 3 (drawn last again): coefficients in registers, non-temporal loads by role, reversed block order of every second
+    # launch, a published output-array position -- none of them may change a result
+    r = rnd.random()
+    if r < 0.15:
+        cl += ["--coef", rnd.choice(["sgpr", "vgpr"])]
+    if rnd.random() < 0.1 and not dma:
+        cl += ["--nt-load", str(rnd.choice([2, 3]))]
+    if rnd.random() < 0.1:
+        cl += ["--zigzag", "1"]
+    if rnd.random() < 0.05:
+        cl += ["--out-skew", str(rnd.choice([0, 8, 40]))]
     return cl
 
 
