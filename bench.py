@@ -845,6 +845,8 @@ def main(argv=None):
         }
         if pworld == 1:
             out["config"]["placement"] = placement
+            out["config"]["finite_data"] = {"overflow_horizon_time_steps": finite_steps, "time_steps_per_step": launches_per_step * step, "steps_per_chunk": chunk,
+                                            "chunks": -(-args.steps // chunk), "note": "the pristine U[0, 1) input is restored before every timed loop (outside the events)"}
         elif slab_placement is not None:
             out["config"]["placement"] = dict(slab_placement, mode="measured, rank %d" % prank)
         if pworld > 1:

@@ -214,6 +214,18 @@ def _run_bench_rehearsal():
         stdout, text = r.stdout, "[rc=%d]\n%s" % (r.returncode, r.stderr[-1500:])
     except Exception as e:
         stdout, text = "", "[exception] %r" % (e,)
+    # ... and the single-GPU line with a step count beyond the overflow horizon of the data (coefficients sum to 1.5: all inf after ~218 time
+    # steps): the timed loop must run in chunks, each from the restored pristine input
+    try:
+        r1 = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "60", "--warmup", "1", "--no-cpu-baseline", "--headline-only"],
+                            capture_output=True, text=True, timeout=300, cwd=ROOT)
+        with open(os.path.join(out, "n1_steps60_stdout.txt"), "w") as f:
+            f.write(r1.stdout)
+        with open(os.path.join(out, "n1_steps60_stderr.txt"), "w") as f:
+            f.write("[rc=%d]\n%s" % (r1.returncode, r1.stderr[-1500:]))
+    except Exception as e:
+        with open(os.path.join(out, "n1_steps60_stderr.txt"), "w") as f:
+            f.write("[exception] %r" % (e,))
     with open(os.path.join(out, "two_ranks_stdout.txt"), "w") as f:
         f.write(stdout)
     with open(os.path.join(out, "two_ranks_stderr.txt"), "w") as f:

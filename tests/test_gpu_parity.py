@@ -478,6 +478,22 @@ def test_bench_stdout_is_one_json_line_with_rccl_up():
     assert rec["roofline"]["bound"] == "hbm" and rec["config"]["exchange_calibration"]["chosen_every"] in (1, 2)
 
 
+def test_bench_times_finite_data_in_chunks():
+    """bench.py --steps 60 at session start: 60 steps x 4 time steps exceed the ~218 time steps after which the shipped coefficients (sum 1.5)
+    have overflowed a float array, so the timed loop runs in two chunks, each from the restored pristine input; one JSON line, verified."""
+    d = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "drstencil_amd", "_kcache", "bench_rehearsal")
+    err = open(os.path.join(d, "n1_steps60_stderr.txt")).read()
+    assert err.startswith("[rc=0]"), err[-1500:]
+    lines = open(os.path.join(d, "n1_steps60_stdout.txt")).read().splitlines()
+    assert len(lines) == 1
+    rec = json.loads(lines[0])
+    fd = rec["config"]["finite_data"]
+    assert rec["steps"] == 60 and rec["verified"] is True and rec["n_gpus"] == 1
+    assert 200 <= fd["overflow_horizon_time_steps"] <= 230 and fd["time_steps_per_step"] == 4 and fd["chunks"] == 2 and fd["steps_per_chunk"] * 4 < fd["overflow_horizon_time_steps"]
+    assert rec["config"]["placement"]["mode"] == "measured" and len(rec["config"]["placement"]["measured_ms_fwd_bwd_by_skew_MiB"]) == 4
+    assert 0.5 < rec["roofline"]["frac"] < 0.9 and abs(rec["ms_per_step"] / (2 * rec["roofline"]["avg_launch_ms"]) - 1.0) < 0.05
+
+
 def test_two_rank_processes_under_the_launcher_verify_themselves():
     """`python -m torch.distributed.run --nproc-per-node 2 bench.py --gpus 2` -- the driver's own form -- rehearsed at session start with
     both rank processes on this one GPU and a gloo group staged in host memory instead of RCCL (conftest._run_bench_rehearsal): rank 0's
