@@ -65,7 +65,11 @@ TUNED = {
     # round 2: + `-fno-slp-vectorize` for this kernel (the SLP vectoriser packs the 200 FMAs per lane and plane into v_pk_fma_f32,
     # whose register-pair operands cost 935 v_mov per 24 planes; without it 202 VGPRs instead of 226 and 0.4-1 % less time in four
     # interleaved comparisons, profiles/r02_exp_r2[a-d]*.log)
-    "c4": ["--3d", "--dtype", "fp32", "--step", "2", "--prefetch", "--prefetch-depth", "3", "--bx", "32", "--by", "16", "--block-merge-x", "4", "--block-merge-y", "2", "--sn", "32", "--xcd-remap", "2", "--cc-opt", "-fno-slp-vectorize"],
+    # round 3, second half: with finite data and the output array's position tuned per configuration, two sweeps (165 + 403 configurations,
+    # profiles/r03_tune_c4_s2_{top165,random700}_placement.txt) and an interleaved comparison (r03_exp_r3q.log: 1.452 ms against 1.488) put a
+    # PINNED 1024-lane kernel first: 64 x 16 lanes (256 x 32 tile), 16-plane blocks, no prefetch, 95 VGPRs.  Rounds 1-3's headline (32 x 16
+    # lanes, 32-plane blocks, prefetch depth 3, 204 VGPRs) stays as SLAB_BASE: the kernels of the N > 1 runs, and a side measurement
+    "c4": ["--3d", "--dtype", "fp32", "--step", "2", "--bx", "64", "--by", "16", "--block-merge-x", "4", "--block-merge-y", "2", "--sn", "16", "--xcd-remap", "2", "--pin", "1", "--cc-opt", "-fno-slp-vectorize"],
     "c3": ["--3d", "--dtype", "fp32", "--step", "2", "--prefetch", "--prefetch-depth", "3", "--bx", "32", "--by", "16", "--block-merge-x", "4", "--block-merge-y", "2", "--sn", "32", "--xcd-remap", "2", "--cc-opt", "-fno-slp-vectorize"],
     # 2D one-shot LDS tiles (BASELINE C2 "no temporal blocking (baseline LDS tile)", C5 "wide-halo LDS staging"): best of the
     # exhaustive 2D searches, profiles/r01_tune_c2_exhaustive.txt / r01_tune_c5_exhaustive.txt (0.78 of the HBM peak each)
@@ -154,8 +158,15 @@ FUSED3 = {
 # 256: 0.380 vs 0.424, 512: 0.758 vs 0.804 -- profiles/r01_exp_r1zj_one_block_per_tile.log, r01_exp_r1zk_...), but its
 # workgroups hold every CU until the launch ends, so the RCCL send/recv kernel cannot start beside it: in the rehearsal
 # a rank of the 8-GPU run drops from 1200 to 1130 GStencil/s.  Short blocks retire every ~20 us and let it in.
+SLAB_BASE = {
+    # the fused step-2 kernel the N > 1 runs cut into slab views (rounds 1-3's single-GPU headline); on 128- and 256-plane views it is as fast as
+    # the new single-GPU headline's shape (profiles/r03_exp_r3r.log), and every slab test and rehearsal of three rounds ran with it
+    "c4": ["--3d", "--dtype", "fp32", "--step", "2", "--prefetch", "--prefetch-depth", "3", "--bx", "32", "--by", "16", "--block-merge-x", "4", "--block-merge-y", "2", "--sn", "32", "--xcd-remap", "2", "--cc-opt", "-fno-slp-vectorize"],
+}
+
+
 def slab_options(workload, world, weak=False):
-    opts = list(TUNED[workload])
+    opts = list(SLAB_BASE.get(workload, TUNED[workload]))
     if workload == "c4" and world >= 4 and not weak:
         # round 3: on 128-plane views the PINNED kernel (122 VGPRs: two workgroups per CU) with 16-plane blocks takes 0.188 ms against 0.200 for
         # round 2's kernel (profiles/r03_exp_r3h.log), and its short blocks still let the RCCL kernel in beside it
@@ -170,7 +181,7 @@ def slab_alone_options(workload, world, weak=False):
     are one workgroup per CU, so one stream block per tile (no z halo, no per-block prologue) is the fastest sweep of a slab of up to 512
     planes (0.186 vs 0.199 ms at 128 planes); None: the same kernels as the exchanging launches."""
     if workload == "c4" and world >= 2 and not weak and os.environ.get("DRS_SLAB_ALONE", "1") != "0":      # 0: A/B experiments
-        opts = list(TUNED[workload])
+        opts = list(SLAB_BASE.get(workload, TUNED[workload]))
         opts[opts.index("--sn") + 1] = "1024"
         return opts
     return None
@@ -184,6 +195,7 @@ def kernels():
     """Every kernel bench.py can time: (id, workload, generator options).  __graft_entry__.build() prebuilds them and
     tests/gpu_cases.py::FULL holds a full-size parity case for each (tests/test_capi_and_tuner.py checks that)."""
     out = [("bench_%s_headline" % w, w, TUNED[w]) for w in sorted(TUNED)]
+    out += [("bench_%s_slab_base" % w, w, SLAB_BASE[w]) for w in sorted(SLAB_BASE)]
     out += [("bench_%s_step1" % w, w, STEP1[w]) for w in sorted(STEP1)]
     out += [("bench_%s_temporal2" % w, w, TEMPORAL2[w]) for w in sorted(TEMPORAL2)]
     out += [("bench_%s_window_two_workgroups" % w, w, WINDOW2WG[w]) for w in sorted(WINDOW2WG)]
@@ -528,7 +540,7 @@ def main(argv=None):
             L *= pworld
         else:
             M *= pworld
-    kern1 = kernf = kernw = None
+    kern1 = kernf = kernw = kernp = None
     kern3 = []
     if pworld == 1:
         kern = drs.Kernel(opts + [w["stc"]])
@@ -541,6 +553,8 @@ def main(argv=None):
                     kern3.append((drs.Kernel(o3 + [w["stc"]]), o3))
                 except drs.KernelBuildError:          # a compiler that needs scratch for it: not a candidate
                     pass
+            if args.workload in SLAB_BASE and not args.kernel_args:
+                kernp = drs.Kernel(SLAB_BASE[args.workload] + [w["stc"]])      # rounds 1-3's headline: side measurement (continuity) and the N > 1 base kernel
             if args.workload in WINDOW2WG:
                 try:
                     kernw = drs.Kernel(WINDOW2WG[args.workload] + [w["stc"]])
@@ -693,6 +707,7 @@ def main(argv=None):
         step1 = side(kern1, STEP1[args.workload], 16) if kern1 is not None else None
         fused2 = side(kernf, TEMPORAL2[args.workload], 32) if kernf is not None else None
         window2 = side(kernw, WINDOW2WG[args.workload], 32) if kernw is not None else None
+        prev_headline = side(kernp, SLAB_BASE[args.workload], 32) if kernp is not None else None
         fused3 = None
         if kern3:
             # every candidate timed on THIS device, on finite data (side() restores the pristine input first), the fastest reported in full
@@ -806,7 +821,7 @@ def main(argv=None):
         if args.slab_runtime == "native":
             calibration = dict(calibration or {}, native_runtime=run.slab.info)
         parallelism = "%s-slab x%d%s, RCCL send/recv halo every %d launch(es), overlapped" % ("z" if w["ndim"] == 3 else "y", pworld, " (weak: grid %s)" % "x".join(str(d) for d in ((L, M, N) if w["ndim"] == 3 else (M, N))) if weak else "", args.exchange_every)
-        step1 = fused2 = window2 = fused3 = None
+        step1 = fused2 = window2 = fused3 = prev_headline = None
         verified, verification, host_slab, first_out = None, None, None, None     # the slab kernels' parity is tests/test_gpu_parity.py::test_c4_slab_views_at_full_size
         if not args.no_verify and not rehearse:      # (a rehearsal's self-neighbour exchange is not the physical one)
             verified, verification = verify_slab_run(torch, dist, run, sweep, (L, M, N) if w["ndim"] == 3 else (M, N), H, launches_per_step, iters, prank, pworld, dev, tdt)
@@ -865,6 +880,8 @@ def main(argv=None):
         out["fused_step3_kernel"] = fused3 if (fused3 and fused3["step"] == 3) else None
         if fused3:
             out["best_bit_exact_GStencil_per_s"] = max(value, fused3["GStencil_per_s"])
+        if prev_headline is not None:
+            out["rounds_1_to_3_headline_kernel"] = prev_headline    # 32 x 16 lanes, 32-plane blocks, prefetch depth 3 (204 VGPRs): the N > 1 runs' base kernel
         out["two_workgroups_per_cu_kernel"] = window2   # the same fused arithmetic from rotating register windows at 126 VGPRs: two workgroups per CU
         if not args.no_cpu_baseline and pworld == 1:
             sys.path.insert(0, ROOT)
