@@ -83,7 +83,9 @@ TUNED = {
     # its box (profiles/r02_tune_c3f64_s2.txt); the interleaved comparison on another box has round 1's scatter kernel 4-5 % ahead at both sizes
     # (profiles/r02_exp_r2i_diagnostics.log: 0.374 vs 0.388 ms at 512^3, 3.04 vs 3.22 ms at 1024^3), so it stays, with -fno-slp-vectorize (+0.3 %)
     "c3f64": ["--3d", "--dtype", "fp64", "--step", "2", "--bx", "128", "--by", "4", "--block-merge-x", "2", "--block-merge-y", "2", "--sn", "32", "--xcd-remap", "2", "--cc-opt", "-fno-slp-vectorize"],
-    "c4f64": ["--3d", "--dtype", "fp64", "--step", "2", "--bx", "128", "--by", "4", "--block-merge-x", "2", "--block-merge-y", "2", "--sn", "32", "--xcd-remap", "2", "--cc-opt", "-fno-slp-vectorize"],
+    # round 3, second half: the pinned 1024-lane shape of the fp32 headline pays in fp64 too at 1024^3: 2.897 ms against 3.087 for round 1's kernel
+    # (128 x 4 lanes, 32-plane blocks) in one process, finite data, arrays placed (profiles/r03_exp_r3s.log); at 512^3 it does not (c3f64 stays)
+    "c4f64": ["--3d", "--dtype", "fp64", "--step", "2", "--bx", "64", "--by", "16", "--block-merge-x", "2", "--block-merge-y", "2", "--sn", "16", "--xcd-remap", "2", "--pin", "1", "--cc-opt", "-fno-slp-vectorize"],
     # shipped specs: the best configurations of profiles/r01_tune_shipped.md at --step 2, the only step the reference's tuner sweeps
     # (benchmarks/*/tuning.py:110): fused kernels (bit-exact) for the order-1 stencils
     "s_2d5pt_star": ["--dtype", "fp64", "--step", "2", "--bx", "128", "--by", "4", "--block-merge-x", "2", "--block-merge-y", "2", "--xcd-remap", "0"],
