@@ -68,7 +68,8 @@ TUNED = {
     # round 3, second half: with finite data and the output array's position tuned per configuration, two sweeps (165 + 403 configurations,
     # profiles/r03_tune_c4_s2_{top165,random700}_placement.txt) and an interleaved comparison (r03_exp_r3q.log: 1.452 ms against 1.488) put a
     # PINNED 1024-lane kernel first: 64 x 16 lanes (256 x 32 tile), 16-plane blocks, no prefetch, 95 VGPRs.  Rounds 1-3's headline (32 x 16
-    # lanes, 32-plane blocks, prefetch depth 3, 204 VGPRs) stays as SLAB_BASE: the kernels of the N > 1 runs, and a side measurement
+    # lanes, 32-plane blocks, prefetch depth 3, 204 VGPRs) stays as PREV_HEADLINE: a side measurement (the N > 1 runs take the new kernel too: -3...4 %
+    # per ping-pong pair in the rehearsals of ranks of 8 and of 4, profiles/r03_bench_rehearse5_*.json)
     "c4": ["--3d", "--dtype", "fp32", "--step", "2", "--bx", "64", "--by", "16", "--block-merge-x", "4", "--block-merge-y", "2", "--sn", "16", "--xcd-remap", "2", "--pin", "1", "--cc-opt", "-fno-slp-vectorize"],
     "c3": ["--3d", "--dtype", "fp32", "--step", "2", "--prefetch", "--prefetch-depth", "3", "--bx", "32", "--by", "16", "--block-merge-x", "4", "--block-merge-y", "2", "--sn", "32", "--xcd-remap", "2", "--cc-opt", "-fno-slp-vectorize"],
     # 2D one-shot LDS tiles (BASELINE C2 "no temporal blocking (baseline LDS tile)", C5 "wide-halo LDS staging"): best of the
@@ -160,31 +161,28 @@ FUSED3 = {
 # 256: 0.380 vs 0.424, 512: 0.758 vs 0.804 -- profiles/r01_exp_r1zj_one_block_per_tile.log, r01_exp_r1zk_...), but its
 # workgroups hold every CU until the launch ends, so the RCCL send/recv kernel cannot start beside it: in the rehearsal
 # a rank of the 8-GPU run drops from 1200 to 1130 GStencil/s.  Short blocks retire every ~20 us and let it in.
-SLAB_BASE = {
-    # the fused step-2 kernel the N > 1 runs cut into slab views (rounds 1-3's single-GPU headline); on 128- and 256-plane views it is as fast as
-    # the new single-GPU headline's shape (profiles/r03_exp_r3r.log), and every slab test and rehearsal of three rounds ran with it
+PREV_HEADLINE = {
+    # rounds 1-3's single-GPU headline (and, until the second half of round 3, the kernel the N > 1 runs cut into slab views): side measurement
     "c4": ["--3d", "--dtype", "fp32", "--step", "2", "--prefetch", "--prefetch-depth", "3", "--bx", "32", "--by", "16", "--block-merge-x", "4", "--block-merge-y", "2", "--sn", "32", "--xcd-remap", "2", "--cc-opt", "-fno-slp-vectorize"],
 }
 
 
 def slab_options(workload, world, weak=False):
-    opts = list(SLAB_BASE.get(workload, TUNED[workload]))
-    if workload == "c4" and world >= 4 and not weak:
-        # round 3: on 128-plane views the PINNED kernel (122 VGPRs: two workgroups per CU) with 16-plane blocks takes 0.188 ms against 0.200 for
-        # round 2's kernel (profiles/r03_exp_r3h.log), and its short blocks still let the RCCL kernel in beside it
-        opts[opts.index("--sn") + 1] = "16"
-        opts[opts.index("--prefetch-depth") + 1] = "2"
-        opts += ["--pin", "1"]
-    return opts
+    """Generator options of the slab-view kernels of an N > 1 run: the workload's single-GPU headline.  (C4: the pinned 64 x 16-lane kernel with
+    16-plane blocks -- short blocks retire every ~10 us and let the RCCL send/recv kernel in beside the interior launch; rounds 1-3 used the
+    32 x 16-lane kernel with 16-plane blocks at 4+ ranks.)"""
+    return list(TUNED[workload])
 
 
 def slab_alone_options(workload, world, weak=False):
-    """Options of the launches that have the GPU to themselves (the whole-slab launch of a one-exchange-per-pair run): C4's 256 tiles
-    are one workgroup per CU, so one stream block per tile (no z halo, no per-block prologue) is the fastest sweep of a slab of up to 512
-    planes (0.186 vs 0.199 ms at 128 planes); None: the same kernels as the exchanging launches."""
-    if workload == "c4" and world >= 2 and not weak and os.environ.get("DRS_SLAB_ALONE", "1") != "0":      # 0: A/B experiments
-        opts = list(SLAB_BASE.get(workload, TUNED[workload]))
-        opts[opts.index("--sn") + 1] = "1024"
+    """Options of the launches that have the GPU to themselves (the whole-slab launch of a one-exchange-per-pair run), or None: the same kernels as
+    the exchanging launches.  Rounds 1-3 used one stream block per tile there (0.186 vs 0.199 ms at 128 planes for the 32 x 16-lane kernel); the
+    pinned 64 x 16-lane kernel with its short blocks is faster than that on every slab length (0.181-0.188 ms; profiles/r03_exp_r3r.log), and ONE
+    block per tile is its worst case (0.231), so since the second half of round 3 there is no separate kernel.  DRS_SLAB_ALONE_SN=<n>: experiments."""
+    sn = os.environ.get("DRS_SLAB_ALONE_SN")
+    if sn and workload == "c4" and world >= 2 and not weak:
+        opts = list(TUNED[workload])
+        opts[opts.index("--sn") + 1] = sn
         return opts
     return None
 
@@ -197,7 +195,7 @@ def kernels():
     """Every kernel bench.py can time: (id, workload, generator options).  __graft_entry__.build() prebuilds them and
     tests/gpu_cases.py::FULL holds a full-size parity case for each (tests/test_capi_and_tuner.py checks that)."""
     out = [("bench_%s_headline" % w, w, TUNED[w]) for w in sorted(TUNED)]
-    out += [("bench_%s_slab_base" % w, w, SLAB_BASE[w]) for w in sorted(SLAB_BASE)]
+    out += [("bench_%s_prev_headline" % w, w, PREV_HEADLINE[w]) for w in sorted(PREV_HEADLINE)]
     out += [("bench_%s_step1" % w, w, STEP1[w]) for w in sorted(STEP1)]
     out += [("bench_%s_temporal2" % w, w, TEMPORAL2[w]) for w in sorted(TEMPORAL2)]
     out += [("bench_%s_window_two_workgroups" % w, w, WINDOW2WG[w]) for w in sorted(WINDOW2WG)]
@@ -555,8 +553,8 @@ def main(argv=None):
                     kern3.append((drs.Kernel(o3 + [w["stc"]]), o3))
                 except drs.KernelBuildError:          # a compiler that needs scratch for it: not a candidate
                     pass
-            if args.workload in SLAB_BASE and not args.kernel_args:
-                kernp = drs.Kernel(SLAB_BASE[args.workload] + [w["stc"]])      # rounds 1-3's headline: side measurement (continuity) and the N > 1 base kernel
+            if args.workload in PREV_HEADLINE and not args.kernel_args:
+                kernp = drs.Kernel(PREV_HEADLINE[args.workload] + [w["stc"]])      # rounds 1-3's headline: side measurement (continuity)
             if args.workload in WINDOW2WG:
                 try:
                     kernw = drs.Kernel(WINDOW2WG[args.workload] + [w["stc"]])
@@ -709,7 +707,7 @@ def main(argv=None):
         step1 = side(kern1, STEP1[args.workload], 16) if kern1 is not None else None
         fused2 = side(kernf, TEMPORAL2[args.workload], 32) if kernf is not None else None
         window2 = side(kernw, WINDOW2WG[args.workload], 32) if kernw is not None else None
-        prev_headline = side(kernp, SLAB_BASE[args.workload], 32) if kernp is not None else None
+        prev_headline = side(kernp, PREV_HEADLINE[args.workload], 32) if kernp is not None else None
         fused3 = None
         if kern3:
             # every candidate timed on THIS device, on finite data (side() restores the pristine input first), the fastest reported in full
@@ -741,8 +739,15 @@ def main(argv=None):
             n1 = torch.zeros(2, dtype=torch.float64, device=cdev)
             if rank == 0:
                 shape1 = (L, M, N) if w["ndim"] == 3 else (M, N)
-                A1 = torch.rand(shape1, dtype=tdt, device=dev)
-                B1 = torch.zeros_like(A1)
+                # the same protocol as the N = 1 line: both arrays in one arena at the measured position, finite data in the timed loops
+                if args.placement == "separate":
+                    A1 = torch.rand(shape1, dtype=tdt, device=dev)
+                    B1 = torch.zeros_like(A1)
+                    arena1 = None
+                else:
+                    A1, B1, arena1 = kern_n1.alloc_pair(torch, dev, dtype=tdt, calibrate=(args.placement == "measured"))
+                R1 = torch.rand(shape1, dtype=tdt, device=dev)
+                A1.copy_(R1); B1.zero_()
                 st1 = torch.cuda.current_stream(dev)
                 tw = time.perf_counter()
                 while time.perf_counter() - tw < MIN_WARM_S:
@@ -751,11 +756,12 @@ def main(argv=None):
                     torch.cuda.synchronize()
                 n_1, ms_1 = 0, 0.0
                 for _ in range(3):
+                    A1.copy_(R1); B1.zero_()
                     a_, b_ = kern_n1.run_timed(A1.data_ptr(), B1.data_ptr(), iterations=4 * iters, warmup=0, stream=st1.cuda_stream)
                     n_1, ms_1 = n_1 + a_, ms_1 + b_
                 n1[0] = kern_n1.updates_per_launch() * n_1 / (ms_1 * 1e-3) / 1e9
                 n1[1] = ms_1 / n_1
-                del A1, B1
+                del A1, B1, R1, arena1
                 torch.cuda.empty_cache()
             dist.all_reduce(n1, op=dist.ReduceOp.MAX)
             n1_value = float(n1[0])
@@ -883,7 +889,7 @@ def main(argv=None):
         if fused3:
             out["best_bit_exact_GStencil_per_s"] = max(value, fused3["GStencil_per_s"])
         if prev_headline is not None:
-            out["rounds_1_to_3_headline_kernel"] = prev_headline    # 32 x 16 lanes, 32-plane blocks, prefetch depth 3 (204 VGPRs): the N > 1 runs' base kernel
+            out["rounds_1_to_3_headline_kernel"] = prev_headline    # 32 x 16 lanes, 32-plane blocks, prefetch depth 3 (204 VGPRs)
         out["two_workgroups_per_cu_kernel"] = window2   # the same fused arithmetic from rotating register windows at 126 VGPRs: two workgroups per CU
         if not args.no_cpu_baseline and pworld == 1:
             sys.path.insert(0, ROOT)

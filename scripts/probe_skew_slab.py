@@ -24,7 +24,9 @@ def main():
             if lv < 32:
                 continue
             ks.append(("w%d_view%d" % (world, lv), lv, drs.Kernel(bench.slab_options("c4", world) + [_write_view_stc(w["stc"], 3, lv, cache, "slabL")])))
-        ks.append(("w%d_alone%d" % (world, sp.Lloc), sp.Lloc, drs.Kernel(bench.slab_alone_options("c4", world) + [_write_view_stc(w["stc"], 3, sp.Lloc, cache, "slabL")])))
+        alone = bench.slab_alone_options("c4", world)      # None since the second half of round 3 (DRS_SLAB_ALONE_SN=1024 brings the one-block-per-tile kernel back)
+        if alone:
+            ks.append(("w%d_alone%d" % (world, sp.Lloc), sp.Lloc, drs.Kernel(alone + [_write_view_stc(w["stc"], 3, sp.Lloc, cache, "slabL")])))
     if os.environ.get("PROBE_BUILD_ONLY"):
         print([k[0] for k in ks])
         return
