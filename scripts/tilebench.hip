@@ -178,7 +178,16 @@ int main()
     const long pad = 64;                                  // floats: 256 bytes
     const size_t elems = (size_t)(N + pad) * M * L + 4096;
     float *a, *b;
-    if (hipMalloc(&a, elems * 4) != hipSuccess || hipMalloc(&b, elems * 4) != hipSuccess) { printf("hipMalloc failed\n"); return 1; }
+    // TILEBENCH_SKEW_MIB=<n> (round 3, second half): both arrays in ONE allocation, the output n MiB (mod 64 MiB) behind the input -- launch time of a
+    // z-streaming kernel depends on (out - in) mod 64 MiB; unset: two separate allocations as in rounds 2-3 (an arbitrary phase)
+    if (getenv("TILEBENCH_SKEW_MIB")) {
+        const size_t period = 64UL << 20, skew = ((size_t)atol(getenv("TILEBENCH_SKEW_MIB")) << 20) % period;
+        const size_t off = (elems * 4 + period - 1) / period * period + skew;
+        char* arena;
+        if (hipMalloc(&arena, off + elems * 4) != hipSuccess) { printf("hipMalloc failed\n"); return 1; }
+        a = (float*)arena; b = (float*)(arena + off);
+        printf("one arena, output %zu MiB (mod 64 MiB) behind the input\n", skew >> 20);
+    } else if (hipMalloc(&a, elems * 4) != hipSuccess || hipMalloc(&b, elems * 4) != hipSuccess) { printf("hipMalloc failed\n"); return 1; }
     (void)hipMemset(a, 0x3c, elems * 4); (void)hipMemset(b, 0, elems * 4);
     for (int padded = 0; padded < (getenv("TILEBENCH_PADDED") ? 2 : 1); padded++) {
         const long pitch = N + (padded ? pad : 0);
