@@ -304,24 +304,25 @@ class Kernel:
         return A, B, arena
 
     def calibrate_skew(self, torch, d_in, d_out0, period, steps=4, launches=4, stream=0):
-        """Time in -> out and out -> in for out = d_out0 + j * period / steps; returns (best skew in bytes, [(skew, ms fwd, ms bwd)]).
-        Four positions, 16 MiB apart: kernels with several z fronts in flight (16 MiB apart for the full-row step-1 kernel) dislike odd
-        multiples of 8 MiB, and the single-front kernels' good zone is 24 MiB wide (profiles/r03_probe_skew5.log).  A position within
-        0.5 % of the best that equals the kernel's own recommendation wins (noise must not move it)."""
-        st = torch.cuda.current_stream() if not stream else None
-        s = st.cuda_stream if st is not None else stream
+        """Time in -> out and out -> in for out = d_out0 + j * period / steps on torch's current stream; returns (best skew in bytes,
+        [(skew, ms fwd, ms bwd)]).  Four positions, 16 MiB apart: kernels with several z fronts in flight (16 MiB apart for the full-row
+        step-1 kernel) dislike odd multiples of 8 MiB, and the single-front kernels' good zone is 24 MiB wide (profiles/r03_probe_skew5.log).
+        A position within 0.5 % of the best that equals the kernel's own recommendation wins (noise must not move it).  (`stream` is
+        accepted for symmetry with launch() and ignored: the events and the launches must share a stream, and that is the current one.)"""
+        st = torch.cuda.current_stream()
+        s = st.cuda_stream
         e = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
         table = []
         for j in range(steps):
             d_out = d_out0 + j * (period // steps)
             self.launch(d_in, d_out, s); self.launch(d_out, d_in, s)
-            e[0].record(st) if st is not None else e[0].record()
+            e[0].record(st)
             for _ in range(launches):
                 self.launch(d_in, d_out, s)
-            e[1].record(st) if st is not None else e[1].record()
+            e[1].record(st)
             for _ in range(launches):
                 self.launch(d_out, d_in, s)
-            e[2].record(st) if st is not None else e[2].record()
+            e[2].record(st)
             torch.cuda.synchronize()
             table.append((j * (period // steps), e[0].elapsed_time(e[1]) / launches, e[1].elapsed_time(e[2]) / launches))
         best = min(table, key=lambda r: r[1] + r[2])
