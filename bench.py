@@ -149,9 +149,12 @@ FUSED3 = {
            ["--dtype", "fp32", "--step", "3", "--bx", "128", "--by", "4", "--block-merge-x", "4", "--block-merge-y", "4", "--xcd-remap", "0", "--order", "rows", "--pack", "0"]],
     # the reference's precision: fused --step 3 in fp64, 899 / 835 GStencil/s against 702 / 704 for the step-2 kernels (profiles/r03_exp_r3f.log)
     "c4f64": [["--3d", "--dtype", "fp64", "--step", "3", "--prefetch", "--prefetch-depth", "1", "--order", "rows", "--bx", "64", "--by", "8", "--block-merge-x", "2", "--block-merge-y", "2", "--sn", "64", "--xcd-remap", "2"],
-              ["--3d", "--dtype", "fp64", "--step", "3", "--prefetch", "--prefetch-depth", "1", "--order", "rows", "--bx", "128", "--by", "4", "--block-merge-x", "2", "--block-merge-y", "2", "--sn", "64", "--xcd-remap", "2"]],
+              ["--3d", "--dtype", "fp64", "--step", "3", "--prefetch", "--prefetch-depth", "1", "--order", "rows", "--bx", "128", "--by", "4", "--block-merge-x", "2", "--block-merge-y", "2", "--sn", "64", "--xcd-remap", "2"],
+              ["--3d", "--dtype", "fp64", "--step", "3", "--xrim", "lds", "--order", "rows", "--bx", "64", "--by", "8", "--block-merge-x", "2", "--block-merge-y", "2", "--sn", "128", "--xcd-remap", "2"],
+              ["--3d", "--dtype", "fp64", "--step", "3", "--order", "rows", "--bx", "64", "--by", "8", "--block-merge-x", "2", "--block-merge-y", "2", "--sn", "128", "--xcd-remap", "2"]],
     "c3f64": [["--3d", "--dtype", "fp64", "--step", "3", "--prefetch", "--prefetch-depth", "1", "--order", "rows", "--bx", "64", "--by", "8", "--block-merge-x", "2", "--block-merge-y", "2", "--sn", "64", "--xcd-remap", "1"],
-              ["--3d", "--dtype", "fp64", "--step", "3", "--prefetch", "--prefetch-depth", "1", "--order", "rows", "--bx", "128", "--by", "4", "--block-merge-x", "2", "--block-merge-y", "2", "--sn", "32", "--xcd-remap", "2"]],
+              ["--3d", "--dtype", "fp64", "--step", "3", "--prefetch", "--prefetch-depth", "1", "--order", "rows", "--bx", "128", "--by", "4", "--block-merge-x", "2", "--block-merge-y", "2", "--sn", "32", "--xcd-remap", "2"],
+              ["--3d", "--dtype", "fp64", "--step", "3", "--xrim", "lds", "--order", "rows", "--bx", "64", "--by", "8", "--block-merge-x", "2", "--block-merge-y", "2", "--sn", "64", "--xcd-remap", "2"]],
     "c3": [_S3 + ["--bx", "64", "--by", "8", "--block-merge-y", "2", "--sn", "64", "--xcd-remap", "1"],
            _S3 + ["--bx", "32", "--by", "16", "--block-merge-y", "2", "--sn", "32", "--xcd-remap", "2"],
            _S3 + ["--xrim", "lds", "--bx", "64", "--by", "8", "--block-merge-y", "2", "--sn", "64", "--xcd-remap", "2"]],      # the fastest on finite data (r03_exp_r3n.log)
