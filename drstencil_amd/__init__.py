@@ -313,6 +313,8 @@ class Kernel:
         s = st.cuda_stream
         e = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
         table = []
+        for _ in range(12):                              # clocks up before the first position is timed (it would look slow otherwise)
+            self.launch(d_in, d_out0 + period // 2, s); self.launch(d_out0 + period // 2, d_in, s)
         for j in range(steps):
             d_out = d_out0 + j * (period // steps)
             self.launch(d_in, d_out, s); self.launch(d_out, d_in, s)
