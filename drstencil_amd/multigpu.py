@@ -329,6 +329,9 @@ def calibrate_slab_placement(torch, run, kernel, positions=(0, 16 << 20, 32 << 2
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
     a = run.A.data_ptr()
     table = []
+    b_ = place_slab_output(run._arena, run.A, positions[len(positions) // 2]).data_ptr()
+    for _ in range(12):                                  # clocks up before the first position is timed
+        kernel.launch(a, b_, st.cuda_stream); kernel.launch(b_, a, st.cuda_stream)
     for sk in positions:
         b = place_slab_output(run._arena, run.A, sk).data_ptr()
         kernel.launch(a, b, st.cuda_stream); kernel.launch(b, a, st.cuda_stream)
