@@ -61,7 +61,9 @@ int drs_kernel_unload(drs_kernel *k);
  *                 "reassociated"  on-chip time steps (--temporal 1 / force): equal to it up to rounding; the generator emits
  *                                  such a kernel only where its drift estimate ("drift_estimate", relative, for the spec's
  *                                  iterations) stays within 1e-6 (fp32) / 1e-12 (fp64), "tolerance_horizon_iterations" is the
- *                                  largest iteration count for which it does, and "temporal_forced": 1 marks --temporal force. */
+ *                                  largest iteration count for which it does, and "temporal_forced": 1 marks --temporal force.
+ *   "out_skew_bytes", "placement_period_bytes": where the output array should sit relative to the input array, modulo the period
+ *                                  (64 MiB): see drs_kernel_pair_layout below. */
 const char *drs_kernel_info(const drs_kernel *k);
 const char *drs_kernel_path(const drs_kernel *k);   /* the loaded shared object */
 /* JSON: vgprs, agprs, sgprs, scratch_bytes_per_lane, sgpr_spill, vgpr_spill, occupancy_waves_per_simd, lds_bytes of
