@@ -578,6 +578,9 @@ def main():
     ap.add_argument("--jobs", type=int, default=16, help="compile workers")
     ap.add_argument("--emit", default="taps", help="comma-separated emissions to sweep: taps (rounds 1-2), pin, rows, rowspk (round 3)")
     ap.add_argument("--extra", default="", help="generator options added to every configuration (e.g. \"--cc-opt -fno-slp-vectorize\")")
+    ap.add_argument("--placement", default=None, choices=["measured", "kernel"],
+                    help="3D grids with planes of 2 MiB or more: time every configuration at four positions of the output array and keep its best (measured, "
+                         "default) or only at the kernel's recommended position (kernel); also DRS_TUNE_PLACEMENT")
     a = ap.parse_args()
     order, ndim, elem_bytes = a.order, (3 if a.is3d else 2), (4 if a.dtype == "fp32" else 8)
     if a.configs_file:
@@ -593,6 +596,8 @@ def main():
         for p in paras[:5]:
             print(cfgToString(p) if not isinstance(p, str) else p, "|", cfgToCommandLine(p) if not isinstance(p, str) else "")
         return
+    if a.placement:
+        os.environ["DRS_TUNE_PLACEMENT"] = a.placement
     res = searchSpace(os.path.abspath(a.stc), a.is3d, a.dtype, paras, a.out, budget_s=a.budget or None, jobs=a.jobs, profile_top=a.profile_top,
                       extra_opts=a.extra.split())
     print("best:")
