@@ -61,7 +61,11 @@ WORKLOADS = {
 # band per XCD.  The exhaustive 1780-configuration search
 # (profiles/r01_tune_c4_s2_exhaustive.txt) puts the 32x16-lane and 64x8-lane fused kernels and the 66x15-lane
 # temporal pipeline within a few per cent of each other; their order changes from device to device.
-TUNED = {
+# Round 4: the option lists are no longer copied by hand from the tuner's logs.  HEADLINE names the PROBLEM each workload's headline kernel
+# solves; geometry and emission options come from the tuner -> generator table (drstencil_amd/tuned_defaults.tsv, maintained by
+# `tuning.py --write-defaults`), the same rows the generator applies when `drstencil` gets no geometry option -- so
+# `drstencil --3d --dtype fp32 --step 2 c4_3d7pt_star_1024.stc` emits exactly TUNED["c4"]'s kernel (tests/test_cli_and_ir.py).
+# Where each row came from (its `source` column) and what was measured against it -- history of the hand-kept dict this replaces:
     # round 2: + `-fno-slp-vectorize` for this kernel (the SLP vectoriser packs the 200 FMAs per lane and plane into v_pk_fma_f32,
     # whose register-pair operands cost 935 v_mov per 24 planes; without it 202 VGPRs instead of 226 and 0.4-1 % less time in four
     # interleaved comparisons, profiles/r02_exp_r2[a-d]*.log)
@@ -70,49 +74,44 @@ TUNED = {
     # PINNED 1024-lane kernel first: 64 x 16 lanes (256 x 32 tile), 16-plane blocks, no prefetch, 95 VGPRs.  Rounds 1-3's headline (32 x 16
     # lanes, 32-plane blocks, prefetch depth 3, 204 VGPRs) stays as PREV_HEADLINE: a side measurement (the N > 1 runs take the new kernel too: -3...4 %
     # per ping-pong pair in the rehearsals of ranks of 8 and of 4, profiles/r03_bench_rehearse5_*.json)
-    "c4": ["--3d", "--dtype", "fp32", "--step", "2", "--bx", "64", "--by", "16", "--block-merge-x", "4", "--block-merge-y", "2", "--sn", "16", "--xcd-remap", "2", "--pin", "1", "--cc-opt", "-fno-slp-vectorize"],
-    "c3": ["--3d", "--dtype", "fp32", "--step", "2", "--prefetch", "--prefetch-depth", "3", "--bx", "32", "--by", "16", "--block-merge-x", "4", "--block-merge-y", "2", "--sn", "32", "--xcd-remap", "2", "--cc-opt", "-fno-slp-vectorize"],
     # 2D one-shot LDS tiles (BASELINE C2 "no temporal blocking (baseline LDS tile)", C5 "wide-halo LDS staging"): best of the
     # exhaustive 2D searches, profiles/r01_tune_c2_exhaustive.txt / r01_tune_c5_exhaustive.txt (0.78 of the HBM peak each)
-    "c2": ["--dtype", "fp32", "--bx", "128", "--by", "2", "--block-merge-x", "4", "--block-merge-y", "2", "--xcd-remap", "0"],
     # round 3: the tile consumed by source row (--order rows: the row's own vector + DPP neighbours just before its FMAs, sums pinned), 8 rows per
     # lane: 0.694 ms against 0.717 for round 2's kernel in the same process (profiles/r03_exp_r3d.log), bit-identical
-    "c5": ["--dtype", "fp64", "--bx", "64", "--by", "4", "--block-merge-x", "2", "--block-merge-y", "8", "--xcd-remap", "0", "--order", "rows"],
     # fp64 (profiles/r01_tune_shipped.md: exhaustive searches at the reference sizes): the 2D tile of 2d5pt_star step 1; fused step 2 in 3D
-    "c2f64": ["--dtype", "fp64", "--bx", "128", "--by", "4", "--block-merge-x", "2", "--block-merge-y", "2", "--xcd-remap", "0"],
     # round 2: a tuner run over the space with the reference's dist dimension put a reuse-schedule kernel (32x8 lanes, --dist 2) 2 % ahead on
     # its box (profiles/r02_tune_c3f64_s2.txt); the interleaved comparison on another box has round 1's scatter kernel 4-5 % ahead at both sizes
     # (profiles/r02_exp_r2i_diagnostics.log: 0.374 vs 0.388 ms at 512^3, 3.04 vs 3.22 ms at 1024^3), so it stays, with -fno-slp-vectorize (+0.3 %)
-    "c3f64": ["--3d", "--dtype", "fp64", "--step", "2", "--bx", "128", "--by", "4", "--block-merge-x", "2", "--block-merge-y", "2", "--sn", "32", "--xcd-remap", "2", "--cc-opt", "-fno-slp-vectorize"],
     # round 3, second half: the pinned 1024-lane shape of the fp32 headline pays in fp64 too at 1024^3: 2.897 ms against 3.087 for round 1's kernel
     # (128 x 4 lanes, 32-plane blocks) in one process, finite data, arrays placed (profiles/r03_exp_r3s.log); at 512^3 it does not (c3f64 stays)
-    "c4f64": ["--3d", "--dtype", "fp64", "--step", "2", "--bx", "64", "--by", "16", "--block-merge-x", "2", "--block-merge-y", "2", "--sn", "16", "--xcd-remap", "2", "--pin", "1", "--cc-opt", "-fno-slp-vectorize"],
     # shipped specs: the best configurations of profiles/r01_tune_shipped.md at --step 2, the only step the reference's tuner sweeps
     # (benchmarks/*/tuning.py:110): fused kernels (bit-exact) for the order-1 stencils
-    "s_2d5pt_star": ["--dtype", "fp64", "--step", "2", "--bx", "128", "--by", "4", "--block-merge-x", "2", "--block-merge-y", "2", "--xcd-remap", "0"],
-    "s_2d5pt_cross": ["--dtype", "fp64", "--step", "2", "--dist", "2", "--bx", "64", "--by", "4", "--block-merge-x", "2", "--block-merge-y", "4", "--xcd-remap", "0"],
-    "s_2d9pt_box": ["--dtype", "fp64", "--step", "2", "--bx", "64", "--by", "4", "--block-merge-x", "2", "--block-merge-y", "4", "--xcd-remap", "0"],
     # 2d9pt_cross (diagonal cross of order 2; the reference's tuner sweeps it at --step 2 --dist 2, benchmarks/2d9pt_cross/tuning.py:127): fused, bit-exact
     # (rows order: 746 GStencil/s against 522 for the taps-order kernel of the same geometry, profiles/r03_exp_r3g.log)
-    "s_2d9pt_cross": ["--dtype", "fp64", "--step", "2", "--bx", "64", "--by", "4", "--block-merge-x", "2", "--block-merge-y", "4", "--xcd-remap", "0", "--order", "rows"],
     # the wide stencils (order 2 / 35 fused taps) are fastest as on-chip temporal pipelines; in fp64 those stay within 1e-12 of the fused
     # arithmetic (measured 1.7e-15), the bar the tests and bench.py's verification hold fp64 temporal kernels to
     # round 3: with the emitter in charge of the registers the FUSED (bit-exact) step-2 kernels of 2d9pt_star and 3d9pt_cross are faster than
     # round 2's temporal pipelines (749 vs 722 and 665 vs 611 GStencil/s in one process, profiles/r03_exp_r3d.log); 2d25pt_box step 2 (81 fp64
     # taps) stays a pipeline (574 vs 519)
-    "s_2d9pt_star": ["--dtype", "fp64", "--step", "2", "--bx", "64", "--by", "4", "--block-merge-x", "2", "--block-merge-y", "4", "--xcd-remap", "0", "--order", "rows"],
-    "s_2d25pt_box": ["--dtype", "fp64", "--step", "2", "--dist", "4", "--temporal", "1", "--streaming", "--prefetch", "--prefetch-depth", "1", "--bx", "128", "--by", "1",
-                     "--block-merge-x", "2", "--cyclic-merge-y", "1", "--sn", "32", "--xcd-remap", "0"],
-    "s_3d9pt_cross": ["--3d", "--dtype", "fp64", "--step", "2", "--schedule", "scatter", "--prefetch", "--prefetch-depth", "1", "--bx", "32", "--by", "16",
-                      "--block-merge-x", "2", "--block-merge-y", "2", "--sn", "32", "--xcd-remap", "2", "--order", "rows"],
+HEADLINE = {
+    "c4": dict(step=2), "c3": dict(step=2), "c2": dict(), "c5": dict(),
+    "c2f64": dict(), "c3f64": dict(step=2), "c4f64": dict(step=2),
+    "s_2d5pt_star": dict(step=2), "s_2d5pt_cross": dict(step=2, dist=2), "s_2d9pt_box": dict(step=2), "s_2d9pt_cross": dict(step=2),
+    "s_2d9pt_star": dict(step=2), "s_2d25pt_box": dict(step=2, dist=4, temporal=1, streaming=True), "s_3d9pt_cross": dict(step=2),
 }
+
+
+def _tuned():
+    from drstencil_amd import tuned_defaults as td
+    rows = td.load()
+    return {w: td.options_for(WORKLOADS[w]["stc"], WORKLOADS[w]["ndim"], WORKLOADS[w]["dtype"], rows=rows, **h) for w, h in HEADLINE.items()}
+
+
+TUNED = _tuned()
 # the same workloads with one time step per launch: highest roofline fraction.  Full-row tiles (256 lanes x 4
 # points = N), 2 lane rows x 4 rows, 4-plane stream blocks, prefetch: the optimum of the exhaustive 1520-configuration
 # search (profiles/r01_tune_c4_s1_exhaustive.txt) -- 80 % of the HBM peak, the chip's measured copy ceiling
-STEP1 = {
-    "c4": ["--3d", "--dtype", "fp32", "--prefetch", "--bx", "256", "--by", "2", "--block-merge-x", "4", "--block-merge-y", "4", "--sn", "4", "--xcd-remap", "2"],
-    "c3": ["--3d", "--dtype", "fp32", "--prefetch", "--bx", "32", "--by", "16", "--block-merge-x", "4", "--block-merge-y", "2", "--sn", "4", "--xcd-remap", "2"],
-}
+STEP1 = {w: __import__("drstencil_amd.tuned_defaults", fromlist=["x"]).options_for(WORKLOADS[w]["stc"], 3, "fp32") for w in ("c4", "c3")}     # the table's step-1 rows
 # on-chip temporal blocking (two applications of the one-step stencil per launch; equal to the fused stencil up to
 # rounding, 6.8e-7 relative at full size): 66 lanes x 4 = 264 columns own 256, so 4 tiles cover N = 1024 exactly
 TEMPORAL2 = {
@@ -227,8 +226,9 @@ def pmc_traffic(workload, option_string):
 def cpu_baseline(workload, step, budget_s=4.0, host_slab=None, gpu_first_launch=None, temporal=False):
     """The CPU leg (the only place bench.py touches oracle/): the oracle (port) timed on the host cores on a bounded z/y-slab
     sample of the workload -- the first slices of the very array the GPU loop started from (host_slab), or seeded random
-    numbers of the same shape -- and, as the checker, one oracle sweep of the first 2*Halo+12 slices against what the timed GPU
-    kernel wrote there in one launch (gpu_first_launch): bit-exact, except temporal blocking (1e-6 relative fp32 / 1e-12 fp64)."""
+    numbers of the same shape -- and, as the checker, one oracle sweep of each slab of 2*Halo+12 slices verify_timed_kernel kept (bottom,
+    across a block boundary, top: gpu_first_launch) against what the timed GPU kernel wrote there in one launch: bit-exact, except
+    temporal blocking (1e-6 relative fp32 / 1e-12 fp64)."""
     import numpy as np
     import oracle
     w = WORKLOADS[workload]
@@ -242,27 +242,33 @@ def cpu_baseline(workload, step, budget_s=4.0, host_slab=None, gpu_first_launch=
     L, M, N = spec.dims
     dt = np.float32 if w["dtype"] == "fp32" else np.float64
     check = None
-    if host_slab is not None and gpu_first_launch is not None:
+    if gpu_first_launch:
+        # the checker: one oracle sweep per slab of the run's own input -- bottom of the grid, across a stream-block / tile-row boundary
+        # in the middle, top of the grid (byte offsets beyond 2^32 at 1024^3) -- against what the timed kernel wrote there in ONE launch
         h = spec.halo
-        nsl = gpu_first_launch.shape[0] + 2 * h
-        sub = np.ascontiguousarray(host_slab[:nsl], dtype=dt)
-        dst = np.zeros_like(sub)
-        cs = oracle.Spec(w["stc"], w["ndim"], step)
-        if w["ndim"] == 3:
-            cs.set_dims(nsl, M, N)
-        else:
-            cs.set_dims(1, nsl, N)
-        oracle.sweep(cs, sub, dst, contract=1)
-        ref = dst[h:nsl - h]
         tol = 1e-6 if w["dtype"] == "fp32" else 1e-12
-        if temporal:
-            sel = (slice(None),) + tuple(slice(h, d - h) for d in ref.shape[1:])
-            rel = float(np.max(np.abs(gpu_first_launch[sel].astype(np.float64) - ref[sel]) / np.maximum(np.abs(ref[sel]), 1e-30)))
-            ok = rel <= tol
-        else:
-            ok = bool(np.array_equal(gpu_first_launch, ref))
-            rel = 0.0 if ok else float(np.max(np.abs(gpu_first_launch.astype(np.float64) - ref) / np.maximum(np.abs(ref), 1e-30)))
-        check = {"ok": bool(ok), "max_rel": rel, "slices": int(nsl), "bit_exact_required": not temporal}
+        check = {"ok": True, "max_rel": 0.0, "bit_exact_required": not temporal, "slabs": []}
+        for sl in gpu_first_launch:
+            sub = np.ascontiguousarray(sl["input"], dtype=dt)
+            nsl = sub.shape[0]
+            dst = np.zeros_like(sub)
+            cs = oracle.Spec(w["stc"], w["ndim"], step)
+            if w["ndim"] == 3:
+                cs.set_dims(nsl, M, N)
+            else:
+                cs.set_dims(1, nsl, N)
+            oracle.sweep(cs, sub, dst, contract=1)
+            ref, got = dst[h:nsl - h], sl["output"]
+            if temporal:
+                sel = (slice(None),) + tuple(slice(h, d - h) for d in ref.shape[1:])
+                rel = float(np.max(np.abs(got[sel].astype(np.float64) - ref[sel]) / np.maximum(np.abs(ref[sel]), 1e-30)))
+                ok = rel <= tol
+            else:
+                ok = bool(np.array_equal(got, ref))
+                rel = 0.0 if ok else float(np.max(np.abs(got.astype(np.float64) - ref) / np.maximum(np.abs(ref), 1e-30)))
+            check["slabs"].append({"position": sl["label"], "first_slice": int(sl["z0"]), "slices": int(nsl), "ok": bool(ok), "max_rel": rel})
+            check["ok"] = bool(check["ok"] and ok)
+            check["max_rel"] = max(check["max_rel"], rel)
     # bounded sample: a slab of the outermost dim (same plane size, same stencil, same dtype)
     if w["ndim"] == 3:
         Ls = min(L, 128)
@@ -305,8 +311,8 @@ def verify_timed_kernel(torch, kern, workload, A, B, temporal):
     """What bench.py timed is what the parity tests check: ONE launch of the timed kernel on the run's own input against the
     emitted gold kernel on the whole grid (the reference's --check path, codegen.hpp:591-627), plus the untouched ring.
     Bit-exact, except temporal blocking (re-associated: 1e-6 relative fp32 / 1e-12 fp64).  A holds the input, B receives the
-    output.  Returns (ok, details, host copy of the first <= 128 slices of A, host copy of the first output slices of B) -- the
-    last two feed the CPU leg (cpu_baseline), which compares them with the oracle."""
+    output.  Returns (ok, details, host copy of the first <= 128 slices of A, [input / output slabs at Kernel.check_slabs positions]) --
+    the last two feed the CPU leg (cpu_baseline), which times the oracle on the first and compares the slabs with it."""
     w = WORKLOADS[workload]
     h = kern.info["halo"]
     tol = 1e-6 if w["dtype"] == "fp32" else 1e-12
@@ -327,11 +333,12 @@ def verify_timed_kernel(torch, kern, workload, A, B, temporal):
     nsl = min(A.shape[0], 2 * h + 12)
     keep = min(A.shape[0], 128 if w["ndim"] == 3 else 4096)
     host = A[:keep].cpu().numpy()
-    first = B[h:nsl - h].cpu().numpy()
+    slabs = [{"label": label, "z0": z0, "input": A[z0:z0 + nsl].cpu().numpy(), "output": B[z0 + h:z0 + nsl - h].cpu().numpy()}
+             for label, z0 in kern.check_slabs(nsl)]
     return bool(gold_ok and ring_ok), {
         "vs_gold_kernel_full_grid": {"ok": bool(gold_ok), "max_rel": rel, "bit_exact_required": not temporal},
         "vs_cpu_oracle_slab": None,       # filled by the CPU leg (cpu_baseline) unless --no-cpu-baseline
-        "ring_untouched": bool(ring_ok), "tolerance": 0.0 if not temporal else tol}, host, first
+        "ring_untouched": bool(ring_ok), "tolerance": 0.0 if not temporal else tol}, host, slabs
 
 
 def _seeded_planes(torch, lo, hi, rest, dtype, device):
@@ -402,6 +409,7 @@ def parse_args(argv=None):
     ap.add_argument("--steps", type=int, default=40)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="c4", choices=sorted(WORKLOADS))
+    ap.add_argument("--trial-steps", type=int, default=3, help="N > 1 with --exchange-every 0: steps of the run itself timed in each exchange mode before the timed loop (the faster mode is taken)")
     ap.add_argument("--kernel-args", default=None, help="override the generator options (space separated)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--scaling", default="strong", choices=["strong", "weak"],
@@ -771,30 +779,84 @@ def main(argv=None):
             n1_launch_ms = float(n1[1])
         else:
             n1_launch_ms = None
+        dims_ = (L, M, N) if w["ndim"] == 3 else (M, N)
+
+        def make_run(ev):
+            """One rank of the slab run with an exchange every `ev` launches: buffers, streams, (native: communicator and graph), placement."""
+            if args.slab_runtime == "native":
+                from drstencil_amd.multigpu import NativeSlabRun
+                r_ = NativeSlabRun(torch, dist, w["stc"], opts, dims_, H, step, iters, prank, world, dev, tdt, every=ev,
+                                   alone_opts=None if args.kernel_args else slab_alone_options(args.workload, pworld, args.scaling == "weak"),
+                                   rehearse_world=pworld if rehearse else 0, cache_dir=os.path.join(ROOT, "drstencil_amd", "_kcache"))
+            else:
+                r_ = (SelfNeighbourRun if rehearse else SlabRun)(torch, dist, dims_, H, step, iters, prank, pworld, sweep, dev, tdt, every=ev)
+            r_.bench_placement = None
+            if args.placement == "measured" and w["ndim"] == 3:
+                # where this rank's output slab sits relative to its input slab, measured with LOCAL launches of the run's longest-lived kernel
+                # (no exchange, nothing collective; DESIGN.md section 3 "Placement of the two arrays")
+                try:
+                    from drstencil_amd.multigpu import calibrate_slab_placement
+                    p_ = r_.plan
+                    kcal = sweep.kernel(p_.Lloc, alone=True) if (p_.every == 2 and sweep.alone_opts is not None) else sweep.kernel(max(p_.views()))
+                    r_.bench_placement = calibrate_slab_placement(torch, r_, kcal)
+                except Exception as e:       # a kernel that is not in the cache, a CPU run: the arrays stay where slab_pair put them
+                    r_.bench_placement = {"skipped": repr(e)}
+            return r_
+
+        def fill_finite(r_, seed):
+            g_ = torch.Generator(device=dev).manual_seed(seed)
+            r_.A.copy_(torch.rand(r_.A.shape, dtype=tdt, device=dev, generator=g_))      # finite data: a few hundred time steps overflow the slab (N = 1 branch)
+            r_.B.zero_()
+            torch.cuda.synchronize()     # the run's streams are not the one that filled A
+
+        def timed_steps(r_, nsteps):
+            """nsteps runs of the reference's loop on the slab between barriers: (wall seconds, event ms, launches), MAX over the ranks."""
+            torch.cuda.synchronize()
+            dist.barrier()
+            torch.cuda.synchronize()
+            e0_, e1_ = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            t0_ = time.perf_counter()
+            e0_.record(r_.main)
+            n_ = 0
+            for _ in range(nsteps):
+                n_ += r_.run()
+            e1_.record(r_.main)
+            torch.cuda.synchronize()
+            dist.barrier()
+            torch.cuda.synchronize()
+            el_ = time.perf_counter() - t0_
+            return el_, e0_.elapsed_time(e1_), n_
+
+        run_alt = None
         if auto_every:
-            args.exchange_every, calibration = measure_exchange_every(torch, dist, (L, M, N) if w["ndim"] == 3 else (M, N), H, prank, pworld, sweep, dev, tdt,
-                                                                       self_neighbour=bool(rehearse))
-        if args.slab_runtime == "native":
-            from drstencil_amd.multigpu import NativeSlabRun
-            run = NativeSlabRun(torch, dist, w["stc"], opts, (L, M, N) if w["ndim"] == 3 else (M, N), H, step, iters, prank, world, dev, tdt, every=args.exchange_every,
-                                alone_opts=None if args.kernel_args else slab_alone_options(args.workload, pworld, args.scaling == "weak"),
-                                rehearse_world=pworld if rehearse else 0, cache_dir=os.path.join(ROOT, "drstencil_amd", "_kcache"))
+            # (1) the model: sweep / exchange / boundary times measured piecewise, MAX over ranks (multigpu.decide_exchange_every);
+            # (2) the trial: the run itself in BOTH modes for a few steps between barriers -- first contact with a real link is not the
+            #     moment to trust a model fitted on one-GPU rehearsals.  The trial decides; the model's choice is reported beside it.
+            model_every, calibration = measure_exchange_every(torch, dist, dims_, H, prank, pworld, sweep, dev, tdt, self_neighbour=bool(rehearse))
+            runs, trial = {}, {}
+            for ev in (1, 2):
+                try:
+                    runs[ev] = make_run(ev)
+                except ValueError:           # slabs too thin for ghosts twice as wide (every rank raises alike: SlabPlan only knows the sizes)
+                    continue
+                fill_finite(runs[ev], 1 + prank)
+                for _ in range(2):
+                    runs[ev].run()
+                el_, _, _ = timed_steps(runs[ev], args.trial_steps)
+                tt = torch.tensor([el_], dtype=torch.float64, device=cdev)
+                dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+                trial[ev] = float(tt[0]) * 1e3 / args.trial_steps
+            chosen = min(trial, key=lambda e_: trial[e_])
+            calibration = dict(calibration, model_every=model_every, trial_steps=args.trial_steps,
+                               trial_ms_per_step={"every_%d" % e_: round(v_, 4) for e_, v_ in sorted(trial.items())}, chosen_every=chosen,
+                               decided_by="trial of the run itself in both modes (MAX over ranks); the piecewise model is reported beside it")
+            args.exchange_every = chosen
+            run = runs.pop(chosen)
+            run_alt = next(iter(runs.values()), None)
         else:
-            run = (SelfNeighbourRun if rehearse else SlabRun)(torch, dist, (L, M, N) if w["ndim"] == 3 else (M, N), H, step, iters, prank, pworld, sweep, dev, tdt, every=args.exchange_every)
-        slab_placement = None
-        if args.placement == "measured" and w["ndim"] == 3:
-            # where this rank's output slab sits relative to its input slab, measured with LOCAL launches of the run's longest-lived kernel
-            # (no exchange, nothing collective; DESIGN.md section 3 "Placement of the two arrays")
-            try:
-                from drstencil_amd.multigpu import calibrate_slab_placement
-                p_ = run.plan
-                kcal = sweep.kernel(p_.Lloc, alone=True) if (p_.every == 2 and sweep.alone_opts is not None) else sweep.kernel(max(p_.views()))
-                slab_placement = calibrate_slab_placement(torch, run, kcal)
-            except Exception as e:       # a kernel that is not in the cache, a CPU run: the arrays stay where slab_pair put them
-                slab_placement = {"skipped": repr(e)}
-        g = torch.Generator(device=dev).manual_seed(1 + prank)
-        run.A.copy_(torch.rand(run.A.shape, dtype=tdt, device=dev, generator=g))
-        torch.cuda.synchronize()     # the run's streams are not the one that filled A
+            run = make_run(args.exchange_every)
+        slab_placement = run.bench_placement
+        fill_finite(run, 1 + prank)
         for _ in range(args.warmup):
             run.run()
         torch.cuda.synchronize()
@@ -802,24 +864,8 @@ def main(argv=None):
         for _ in range(nwarm):
             run.run()
             warm_extra += 1
-        torch.cuda.synchronize()
-        run.A.copy_(torch.rand(run.A.shape, dtype=tdt, device=dev, generator=g))      # finite data in the timed loop: the warm-up has overflowed the slab (N = 1 branch)
-        run.B.zero_()
-        torch.cuda.synchronize()
-        dist.barrier()
-        torch.cuda.synchronize()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        t0 = time.perf_counter()
-        e0.record(run.main)
-        n = 0
-        for _ in range(args.steps):
-            n += run.run()
-        e1.record(run.main)
-        torch.cuda.synchronize()
-        dist.barrier()
-        torch.cuda.synchronize()
-        el = time.perf_counter() - t0
-        ev_ms = e0.elapsed_time(e1)
+        fill_finite(run, 101 + prank)      # finite data in the timed loop: the warm-up has overflowed the slab (N = 1 branch)
+        el, ev_ms, n = timed_steps(run, args.steps)
         mine = torch.tensor([el * 1e3 / max(args.steps, 1)], dtype=torch.float64, device=cdev)
         per_rank = [torch.zeros_like(mine) for _ in range(world)]
         dist.all_gather(per_rank, mine)
@@ -827,6 +873,29 @@ def main(argv=None):
         t = torch.tensor([el, ev_ms], dtype=torch.float64, device=cdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         el, ev_ms = float(t[0]), float(t[1])
+        # A/B in the same run: the mode that was NOT chosen, same protocol, same number of steps (side measurement: `value` is the chosen mode's)
+        exchange_ab = None
+        if run_alt is not None:
+            fill_finite(run_alt, 101 + prank)
+            for _ in range(2):
+                run_alt.run()
+            fill_finite(run_alt, 101 + prank)
+            el_a, _, _ = timed_steps(run_alt, args.steps)
+            ta = torch.tensor([el_a], dtype=torch.float64, device=cdev)
+            dist.all_reduce(ta, op=dist.ReduceOp.MAX)
+            exchange_ab = {"every_%d_ms_per_step" % run.plan.every: el * 1e3 / args.steps, "every_%d_ms_per_step" % run_alt.plan.every: float(ta[0]) * 1e3 / args.steps,
+                           "value_is": "every_%d" % run.plan.every, "steps_each": args.steps}
+        # what one exchanging launch is made of, per rank (collective: the exchanges pair up), and who the ranks are
+        tl = run.timeline(4) if hasattr(run, "timeline") else None
+        try:
+            rccl = ".".join(str(x) for x in torch.cuda.nccl.version()) if backend == "nccl" else backend
+        except Exception as e:
+            rccl = repr(e)
+        me = {"rank": prank, "device_ordinal": gpu_index, "device": device_info(torch, dev), "rccl": rccl, "every": run.plan.every,
+              "planes_owned": run.plan.z1 - run.plan.z0, "ms_per_step": rank_ms_per_step[rank],
+              "calibration": (calibration or {}).get("this_rank"), "launch_timeline_us": tl, "slab_placement": run.bench_placement}
+        rank_reports = [None] * world
+        dist.all_gather_object(rank_reports, me)
         kinfo = sweep.kernel(run.plan.interior[1] - run.plan.interior[0]).info
         kres = sweep.kernel(run.plan.interior[1] - run.plan.interior[0]).resources
         if args.slab_runtime == "native":
@@ -877,6 +946,8 @@ def main(argv=None):
             out["config"]["placement"] = dict(slab_placement, mode="measured, rank %d" % prank)
         if pworld > 1:
             out["rank_ms_per_step"] = rank_ms_per_step
+            out["ranks"] = rank_reports          # per rank: device, RCCL version, exchange mode, its own calibration numbers, the launch timeline
+            out["exchange_ab"] = exchange_ab      # both exchange modes timed in this run (None when --exchange-every fixed one)
             if n1_value:
                 # strong and weak alike: N GPUs against N times one GPU's rate (a rehearsal's value is ONE rank's share of the work)
                 out["efficiency_vs_n1"] = value / n1_value if rehearse else value / (pworld * n1_value)

@@ -234,6 +234,28 @@ class Kernel:
             raise RuntimeError("HIP error in drs_kernel_run")
         return n
 
+    def check_slabs(self, nsl):
+        """Where a checker should look: [(label, first slice)] of `nsl`-slice slabs of the outermost dimension -- the bottom of the grid, a slab
+        ACROSS a stream-block (z-streaming / row-streaming kernels) or tile-row (one-shot 2D tiles) boundary in the middle, where two
+        workgroups' ownership meets, and the top, where byte offsets are largest (beyond 2^32 at 1024^3).  The caller runs its reference
+        (the CPU oracle in tests/ and bench.py's cpu_baseline leg) on in[z0 : z0 + nsl] and compares out[z0 + Halo : z0 + nsl - Halo]."""
+        i = self.info
+        dim0 = i["L"] if i["ndim"] == 3 else i["M"]
+        nsl = min(nsl, dim0)
+        if i.get("streams", 1):
+            edge = i["halo"] + (i.get("stream_blocks", 1) // 2) * i.get("sn", dim0)       # first output slice of the middle stream block
+        else:
+            edge = (i.get("tiles_y", 1) // 2) * i.get("tile_owned_rows", dim0)             # first row of the middle tile row
+        if not (i["halo"] < edge < dim0 - i["halo"]):
+            edge = dim0 // 2
+        mid = max(0, min(dim0 - nsl, edge - nsl // 2))
+        out = [("bottom", 0)]
+        if mid > 0 and mid < dim0 - nsl:
+            out.append(("block_boundary", mid))
+        if dim0 - nsl > 0:
+            out.append(("top", dim0 - nsl))
+        return out
+
     def run_timed(self, d_a, d_b, iterations=None, warmup=10, stream=0):
         """Warm-up launches + timed loop bracketed by HIP events on `stream`: (launches, ms)."""
         it = self.info["iterations"] if iterations is None else iterations

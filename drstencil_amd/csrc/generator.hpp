@@ -5,14 +5,41 @@
 // unknown flag is "Illegal input." exit 0; `-o` without a value is ignored), plus
 // additive MI355X options that the reference does not have.
 #pragma once
+#include <cmath>
 #include <fstream>
+#include <sstream>
 #include <string>
 #include <vector>
 #include "emit_hip.hpp"
 #include "planner.hpp"
 #include "stencil_ir.hpp"
+#include "tuned_defaults.hpp"
 
 namespace drs {
+
+// ---- tuner -> generator feedback (round 4; reference: benchmarks/3d7pt_star/tuning.py:125-131 ends with the best configuration in
+// duration.log).  tuned_defaults.hpp is generated from drstencil_amd/tuned_defaults.tsv, which `tuning.py --write-defaults` maintains.
+inline unsigned tuned_shape_hash(const CoefTable &base) {          // FNV-1a over "k,j,i;" of the one-step stencil's offsets in map order
+    unsigned h = 0x811c9dc5u;
+    for (auto &e : base.v) {
+        char b[64];
+        snprintf(b, sizeof b, "%d,%d,%d;", e.first.k, e.first.j, e.first.i);
+        for (const char *c = b; *c; c++) h = (h ^ (unsigned char)*c) * 0x01000193u;
+    }
+    return h;
+}
+// the row of this problem class whose N is nearest in log2 (within a factor of sqrt 2), or nullptr
+inline const TunedDefault *tuned_lookup(const char *mode, unsigned shape, int step, const std::string &dtype, int temporal, int N) {
+    const TunedDefault *best = nullptr;
+    double bestd = 0.0;
+    for (int i = 0; i < kTunedDefaultsCount; i++) {
+        const TunedDefault &r = kTunedDefaults[i];
+        if (std::string(r.mode) != mode || r.shape != shape || r.step != step || dtype != r.dtype || r.temporal != temporal || N <= 0) continue;
+        const double d = std::fabs(std::log2((double)N / (double)r.N));
+        if (d <= 0.5 + 1e-9 && (!best || d < bestd)) { best = &r; bestd = d; }
+    }
+    return best;
+}
 
 struct GenResult {
     int exit_code = 0;
@@ -23,6 +50,7 @@ struct GenResult {
     Stencil st;
     KernelPlan plan;
     GenOptions opt;
+    std::string tuned_from;   // non-empty: the geometry / emission options came from the tuned-defaults table (this row's option string)
 };
 
 inline const char *help_text() {
@@ -57,7 +85,7 @@ Options:
 
 --block-merge-y <num>   Specify the number of adjacent rows per lane along dimension y.
 
---cyclic-merge-x <num>  Specify the number of points per lane along dimension x (laid out contiguously).
+--cyclic-merge-x <num>  Specify the number of points per lane along dimension x, bx columns apart.
 
 --cyclic-merge-y <num>  Specify the number of rows per lane along dimension y, by rows apart.
 
@@ -113,6 +141,12 @@ MI355X options:
                         re-associate the fused sum: 1 emits them only where the estimated drift from the reference's
                         fused arithmetic stays within 1e-6 relative (fp32; 1e-12 fp64) for the spec's `iterations`
                         and emits the fused kernel otherwise (a note says so); force emits them regardless.
+--skew <0|1|2>          Temporal pipelines of streaming kernels: 1 = stage t consumes what stage t-1 completed one iteration EARLIER, so the
+                        stages of an iteration are independent and share two barriers instead of one write/barrier/read round per stage;
+                        2 = also double-buffers the intermediate planes' LDS slots (compact, no pads), so completed planes are written
+                        during the compute phase instead of in a burst between the two barriers.
+--tuned-defaults <0|1>  1 (default): a command line without any geometry / emission option takes them from the tuner's table for
+                        this stencil shape, step, dtype and grid size (drstencil_amd/tuned_defaults.tsv), when it has a row.
 --prefetch-depth <n>    With --prefetch: planes in flight ahead of the one being summed (n+1 register sets; default 3 (fp32) /
                         2 (fp64) for fused multi-step 3D kernels, else 1).
 --pair-launch <0|1>     Also emit dr2_<name>(in0, out0, in1, out1): the same sweep over two buffer pairs in one launch.
@@ -142,7 +176,9 @@ MI355X options:
 --xcd-remap <0|1|2>     workgroup to tile mapping: 0 dispatch order, 1 contiguous chunk of tiles
                         per XCD, 2 one x-y band per XCD with all XCDs on the same stream block
                         (default: 2 for 3D, 0 for 2D); 3 = like 2 with --zgroup <n> successive stream
-                        blocks of a tile taken by consecutive workgroups.
+                        blocks of a tile taken by consecutive workgroups; 4 = units of 32 consecutive tiles of one
+                        stream block (the CUs of an XCD) dealt round-robin to the XCDs: neighbouring tiles run
+                        together on one XCD and share their halo reads in its L2.
 --nt-store <0|1>        Non-temporal stores of the output (1 by default).
 --nt-load <0|1>         Non-temporal loads of the input.
 --waves-per-eu <num>    Second argument of __launch_bounds__.
@@ -172,6 +208,9 @@ inline GenResult generate(const std::vector<std::string> &args /* argv[1..] */) 
             if (i != argc - 2) { dst = arg(++i); return true; }
             res.messages += "Illegal input.\n"; res.exit_code = 255; illegal_exit = true; return false;
         };
+        // options that NAME the problem or the artefact; every other option is a tuning choice and switches the tuned-defaults table off
+        if (!(a == "-o" || a == "--3d" || a == "--step" || a == "--streaming" || a == "--check" || a == "--gold" || a == "--dtype" || a == "--gpus" ||
+              a == "--pair-launch" || a == "--temporal" || a == "--dist" || a == "--tuned-defaults" || a == "--out-skew")) o.tuning_given = true;
         if (a == "-o") { if (i != argc - 2) { o.out_name = arg(++i); o.out_set = true; } }
         else if (a == "--3d") o.is3d = true;
         else if (a == "--step") { if (!int_opt(o.step, nullptr)) break; }
@@ -208,6 +247,8 @@ inline GenResult generate(const std::vector<std::string> &args /* argv[1..] */) 
         }
         else if (a == "--loader-waves") { if (!int_opt(o.loader_waves, nullptr)) break; }
         else if (a == "--rot-mod") { if (!int_opt(o.rot_mod, nullptr)) break; }
+        else if (a == "--skew") { if (!int_opt(o.skew, nullptr)) break; }
+        else if (a == "--tuned-defaults") { if (!int_opt(o.tuned_defaults, nullptr)) break; }
         else if (a == "--pin") { if (!int_opt(o.pin, nullptr)) break; }
         else if (a == "--exact-y") { if (!int_opt(o.exact_y, nullptr)) break; }
         else if (a == "--exact-x") { if (!int_opt(o.exact_x, nullptr)) break; }
@@ -258,6 +299,25 @@ inline GenResult generate(const std::vector<std::string> &args /* argv[1..] */) 
     Stencil &st = res.st;
     st.ndim = o.is3d ? 3 : 2;
     if (st.read_stc(stcfile) != 0) { res.messages += "Error opening stencil file.\n"; res.exit_code = 255; return res; }
+    // No geometry / emission option on the command line: the tuner's winner for this problem class, if it has one, supplies them
+    // (drstencil_amd/tuned_defaults.tsv).  The command is re-read with the row's options in front of the .stc, so the banner's
+    // `options:` line, the kernel info and the cache key are those of the explicit command line.
+    if (o.tuned_defaults && !o.tuning_given && !o.ref_defaults) {
+        int order = 0;
+        for (auto &e : st.pts.v) order = std::max(order, std::abs(st.ndim == 3 ? e.first.k : e.first.j));
+        const char *mode = st.ndim == 3 ? "3d" : (o.streaming ? "2ds" : "2d");
+        if (const TunedDefault *t = tuned_lookup(mode, tuned_shape_hash(st.pts), o.step, o.dtype, (o.temporal && o.step > 1) ? 1 : 0, st.N)) {
+            std::vector<std::string> again(args.begin(), args.end() - 1);
+            std::istringstream is(t->options);
+            for (std::string w; is >> w;) again.push_back(w);
+            again.push_back("--tuned-defaults"); again.push_back("0");
+            again.push_back(args.back());
+            GenResult r2 = generate(again);
+            r2.tuned_from = t->options;
+            if (r2.emitted) r2.messages += std::string("drstencil: note: no geometry option given: the tuner's configuration for this stencil, step, dtype and grid size is used (") + t->options + "); --tuned-defaults 0 keeps the generic defaults\n";
+            return r2;
+        }
+    }
     st.fuse(o.step);
     st.choose_halo_dist(o.dist);
     if (st.partition_reuse(o.merge_forward) != REUSE_OK) { res.messages += "No data to reuse. You can try another dist.\n"; res.exit_code = 1; return res; }
@@ -268,6 +328,7 @@ inline GenResult generate(const std::vector<std::string> &args /* argv[1..] */) 
     // 98-114 in the rows order; 1880-2080 against 430 GStencil/s at 1024^3) and one-shot 2D tiles of more than 9 taps (2d25pt_box: +6 %,
     // profiles/r03_exp_r3d.log).  Everything else keeps round 2's emission, which measured faster there (the memory-bound step-2 headline).
     if (!o.order_set && !o.ref_defaults && !o.temporal && o.schedule == "scatter" && o.stage == "reg" && std::max(o.bmy, o.cmy) == std::max(o.bmy, 1) &&
+        !(o.cmx > 1 && o.cmx >= o.bmx) &&
         ((st.ndim == 3 && st.pts.size() > 25) || (st.ndim == 2 && !o.streaming && st.pts.size() > 9))) {
         o.order = "rows";
         if (o.pack < 0) o.pack = 0;       // packed pairs buy nothing with four waves per SIMD

@@ -7,9 +7,10 @@
 //                       best as a multiple of 64 (one wavefront = 64 lanes of x)
 //   --block-merge-x n   n CONTIGUOUS points per lane in x -> one 16-byte
 //                       global_load_dwordx4 per lane for n=4 fp32 / n=2 fp64
-//   --cyclic-merge-x n  same tile width (n*bx); on a 64-wide wavefront strided
-//                       points would turn every row into n dword loads, so the
-//                       points are laid out contiguously as well
+//   --cyclic-merge-x n  the reference's cyclic merge (codegen.hpp:116-141: `mi += blockDim.x`): n points
+//                       per lane, bx columns apart -- every row becomes n element-wide accesses per
+//                       lane (a wavefront instruction = 64 consecutive elements); measured slower
+//                       than block merging on MI355X, kept as the reference's knob
 //   --block-merge-y n   n adjacent rows per lane (y taps between them stay in VGPRs)
 //   --cyclic-merge-y n  n rows per lane, `by` apart
 //   --sn                planes (3D) / rows (2D --streaming) streamed per workgroup
@@ -154,6 +155,13 @@ struct GenOptions {
     int out_skew = -1;           // --out-skew <MiB>: where the output array should sit relative to the input array, modulo 64 MiB (see
                                  // HipEmitter::out_skew_bytes; -1: chosen by the generator).  It changes no kernel text: the value is published
                                  // in the info JSON / the banner and honoured by the emitted host program, which owns its allocations
+    int tuned_defaults = 1;      // --tuned-defaults 0: never consult the tuner's table (generator.hpp)
+    bool tuning_given = false;   // some option other than the problem-naming ones was given
+    int skew = 0;                // --skew 1 (round 4; temporal pipelines of streaming kernels, with --prefetch): stage t consumes the plane stage t-1 completed
+                                 // in the PREVIOUS iteration.  All stages of one iteration are then independent of each other: they run back to back
+                                 // between two barriers -- [barrier] every stage reads its arriving plane's rim from its own LDS slot, the last stage first
+                                 // (its stores leave early) [barrier] every stage's completed plane and the next source plane are written to the slots --
+                                 // instead of write / barrier / read once per stage; costs stages - 1 more prologue iterations per stream block
     int coef_sgpr = 0;           // --coef sgpr: fp32 coefficient values in scalar registers instead of 32-bit literals (4-byte instead of 8-byte FMAs)
     int row_fence = 0;           // mask of __builtin_amdgcn_sched_barrier between row groups (0: nothing crosses; -1: no fence)
 };
@@ -185,6 +193,7 @@ struct KernelPlan {
     // geometry
     int BX = 64, BY = 4, VX = 4, RY = 1, SN = 16;
     bool cyclic_y = false;
+    bool cyclic_x = false;   // --cyclic-merge-x n > 1 (and no larger --block-merge-x): a lane's n points are BX columns apart
     int VL = 4;              // elements per vector memory access
     int NV = 1;              // vectors per row per lane
     int TX = 256, TY = 4;    // lanes' footprint (tile without the exchanged x halo)

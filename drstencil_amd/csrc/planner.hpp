@@ -190,6 +190,7 @@ inline KernelPlan make_plan(const Stencil &st, const GenOptions &o_in, const std
     }
     p.prefetch = o.prefetch || (o_in.step > 1 && st.ndim == 3 && !o.ref_defaults && o.prefetch_auto);
     const bool bmerge_y = o.bmy > o.cmy;
+    const bool bmerge_x = o.bmx > o.cmx;       // main.cpp:232-235
     const int mx = std::max(o.bmx, o.cmx), my = std::max(o.bmy, o.cmy);
 
     // role mapping (streamed, row, col)
@@ -227,6 +228,7 @@ inline KernelPlan make_plan(const Stencil &st, const GenOptions &o_in, const std
     p.BY = p.has_y ? o.by : 1;
     p.RY = p.has_y ? my : 1;
     p.cyclic_y = p.has_y && !bmerge_y && my > 1;
+    p.cyclic_x = !bmerge_x && mx > 1;
     p.SN = p.has_s ? std::max(1, o.sn) : 1;
     p.NT = p.BX * p.BY;
     if (p.BX < 1 || p.BY < 1 || p.NT > 1024) { p.error = "workgroup must have 1..1024 threads"; return p; }
@@ -234,6 +236,7 @@ inline KernelPlan make_plan(const Stencil &st, const GenOptions &o_in, const std
     // vector width of memory accesses: 16 bytes when rows stay 16-byte aligned
     int vl = p.fp32 ? 4 : 2;
     while (vl > 1 && (p.VX % vl != 0 || st.N % vl != 0)) vl >>= 1;
+    if (p.cyclic_x) vl = 1;                    // a lane's points are BX columns apart: element-wide accesses
     p.VL = vl; p.NV = p.VX / vl;
     p.TX = p.BX * p.VX;
     p.TY = p.BY * p.RY;
@@ -266,6 +269,7 @@ inline KernelPlan make_plan(const Stencil &st, const GenOptions &o_in, const std
         if (p.stages > 1) { p.error = "--stage dma: on-chip stages exchange through LDS writes"; return p; }
         if (p.VL * (p.fp32 ? 4 : 8) != 16) { p.error = "--stage dma needs 16-byte vectors (N and the x merge factor multiples of 4 fp32 / 2 fp64)"; return p; }
         if (p.cyclic_y) { p.error = "--stage dma needs block y merging"; return p; }
+        if (p.cyclic_x) { p.error = "--stage dma needs block x merging"; return p; }
         if (!o.clamp_loads || o.halo_spread) { p.error = "--stage dma needs --clamp-loads 1 --halo-spread 0"; return p; }
         if (p.has_y && !p.exact_y) { p.error = "--stage dma needs --exact-y 1"; return p; }
         if (!p.exact_x) { p.error = "--stage dma needs --exact-x 1"; return p; }

@@ -257,9 +257,16 @@ int drs_slab_connect(drs_slab *s, const void *id128, void *main_stream) {
 }
 
 // The reference's loop (codegen.hpp:581-584) on the slab; result in A.  Asynchronous on the slab's main stream.  Returns the
-// number of launches (two per pair, whatever the number of kernels each is made of) or -1 (drs_slab_error).
+// number of launches (two per pair, whatever the number of kernels each is made of), -1 (drs_slab_error), or -3 when a view kernel is a
+// temporal pipeline (not forced) and `iterations` exceeds its tolerance horizon (the rule of drs_kernel_run).
 int drs_slab_run(drs_slab *s, void *d_a, void *d_b, int iterations) {
     const int it = iterations >= 0 ? iterations : s->iterations;
+    // like drs_kernel_run: a view kernel that is an on-chip temporal pipeline keeps the tolerance up to its horizon only
+    for (drs_kernel *k : {s->k_top, s->k_bot, s->k_pair, s->k_interior, s->k_full})
+        if (k && k->horizon >= 0 && !k->forced && it > k->horizon) {
+            s->error = "iterations " + std::to_string(it) + " exceed the tolerance horizon (" + std::to_string(k->horizon) + ") of the slab's temporal kernels: open the slab without --temporal (or with --temporal force)";
+            return -3;
+        }
     const bool want_graph = !(getenv("DRS_SLAB_GRAPH") && getenv("DRS_SLAB_GRAPH")[0] == '0');
     if (want_graph && (s->graph_state == 0 || (s->graph_state == 1 && (s->graph_a != d_a || s->graph_b != d_b)))) {
         // capture one pair for these buffers: the side stream joins the capture through event b and leaves it through event c

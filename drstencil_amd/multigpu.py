@@ -110,15 +110,31 @@ def choose_exchange_every(planes_per_rank, plane_bytes, H, link_GBps=60.0, kerne
     return 2 if planes_per_rank >= 8 * H and sweep_us >= 1.3 * xfer_us else 1
 
 
+def decide_exchange_every(sweep_us, x1_us, x2_us, b1_us, b2_us, planes, H):
+    """The decision rule of measure_exchange_every on its (MAX-over-ranks) inputs: estimated time of one ping-pong pair with an exchange
+    of H planes per face beside EACH launch's interior sweep (every = 1) against one exchange of 2H planes beside the second launch's
+    sweep after a whole-slab launch that recomputes 2H ghost planes (every = 2).  A slow link (x2 > sweep) flips the choice to 1:
+    the 2H-plane transfer no longer hides under one sweep, two H-plane transfers still hide under two.  Returns (every, pair1, pair2)."""
+    pair1 = 2.0 * (b1_us + max(sweep_us, x1_us))
+    pair2 = sweep_us * (1.0 + 2.0 * H / planes) + b2_us + max(sweep_us, x2_us)
+    return (2 if planes >= 8 * H and pair2 < pair1 else 1), pair1, pair2
+
+
 def measure_exchange_every(torch, dist, dims, H, rank, world, sweep, device, dtype, reps=6, self_neighbour=False):
     """The same decision as choose_exchange_every, from numbers measured on the machine the run is on (called during
     warm-up, before the slab buffers exist): one interior sweep of this rank's slab against one exchange of 2H planes per
     face (and of H planes) with the real neighbours through the real process group; MAX over ranks, so every rank
-    decides alike: the mode with the shorter estimated ping-pong pair wins.  Returns (every, measurements)."""
+    decides alike (checked: the choices are gathered, and a disagreement -- NaNs, a rank with different code -- makes everybody
+    take every = 1, the mode that needs nothing of the other ranks' layout): the mode with the shorter estimated ping-pong pair
+    wins (decide_exchange_every).  On a CPU device (the gloo tests) the same measurements are taken with the wall clock.
+    Returns (every, measurements); measurements["this_rank"] holds the rank's own numbers before the MAX."""
+    import time as _time
     dims = tuple(dims)
     p = SlabPlan(dims[0], H, world, rank, 1)
     rest = dims[1:]
-    main = torch.cuda.current_stream(device)
+    gpu = getattr(device, "type", str(device)) == "cuda"
+    main = torch.cuda.current_stream(device) if gpu else None
+    handle = main.cuda_stream if gpu else 0
     src = torch.zeros((p.Lloc,) + rest, dtype=dtype, device=device)
     dst = torch.zeros_like(src)
     a, b = p.interior
@@ -126,6 +142,11 @@ def measure_exchange_every(torch, dist, dims, H, rank, world, sweep, device, dty
     def timed(fn):
         for _ in range(2):
             fn()
+        if not gpu:
+            t0 = _time.perf_counter()
+            for _ in range(reps):
+                fn()
+            return (_time.perf_counter() - t0) / reps * 1e6
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record(main)
@@ -137,7 +158,7 @@ def measure_exchange_every(torch, dist, dims, H, rank, world, sweep, device, dty
 
     # a rank that owns exactly 2H planes has no interior view (SlabRun.launch skips it as well): nothing to time, and asking
     # for a kernel without interior would raise here while the other ranks wait in all_reduce
-    sweep_us = timed(lambda: sweep(src[a:b], dst[a:b], main.cuda_stream)) if b - a > 2 * H else 0.0
+    sweep_us = timed(lambda: sweep(src[a:b], dst[a:b], handle)) if b - a > 2 * H else 0.0
     up = 0 if self_neighbour else rank - 1
     dn = 0 if self_neighbour else rank + 1
     has_up, has_dn = (p.has_up or self_neighbour), (p.has_dn or self_neighbour)
@@ -164,31 +185,39 @@ def measure_exchange_every(torch, dist, dims, H, rank, world, sweep, device, dty
             return 0.0
         s2 = torch.zeros((pe.Lloc,) + rest, dtype=dtype, device=device)
         d2 = torch.zeros_like(s2)
-        ev = torch.cuda.Event()
+        ev = torch.cuda.Event() if gpu else None
 
         def boundary():
             if pe.pair_view() and hasattr(sweep, "pair"):
-                sweep.pair(s2[pe.top[0]:pe.top[1]], d2[pe.top[0]:pe.top[1]], s2[pe.bot[0]:pe.bot[1]], d2[pe.bot[0]:pe.bot[1]], main.cuda_stream)
+                sweep.pair(s2[pe.top[0]:pe.top[1]], d2[pe.top[0]:pe.top[1]], s2[pe.bot[0]:pe.bot[1]], d2[pe.bot[0]:pe.bot[1]], handle)
             else:
                 for v in (pe.top, pe.bot):
                     if v is not None:
-                        sweep(s2[v[0]:v[1]], d2[v[0]:v[1]], main.cuda_stream)
-            ev.record(main)
+                        sweep(s2[v[0]:v[1]], d2[v[0]:v[1]], handle)
+            if ev is not None:
+                ev.record(main)
         return timed(boundary) if (pe.top is not None or pe.bot is not None) else 0.0
 
     planes = min(slab_bounds(dims[0], world, r)[1] - slab_bounds(dims[0], world, r)[0] for r in range(world))
     b1 = boundary_us(1)
     b2 = boundary_us(2) if planes >= 8 * H else b1
-    t = torch.tensor([sweep_us, x1, x2, b1, b2], dtype=torch.float64, device=coll_device(torch, dist, device))
+    mine = {"interior_sweep_us": sweep_us, "exchange_H_planes_us": x1, "exchange_2H_planes_us": x2, "boundary_launch_us_every1": b1, "boundary_launch_us_every2": b2}
+    cdev = coll_device(torch, dist, device)
+    t = torch.tensor([sweep_us, x1, x2, b1, b2], dtype=torch.float64, device=cdev)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     sweep_us, x1, x2, b1, b2 = (float(v) for v in t)
     # time of one ping-pong pair (two launches) in each mode: boundary launch, then the interior sweep beside the exchange
-    pair1 = 2.0 * (b1 + max(sweep_us, x1))
-    pair2 = sweep_us * (1.0 + 2.0 * H / planes) + b2 + max(sweep_us, x2)
-    every = 2 if planes >= 8 * H and pair2 < pair1 else 1
+    every, pair1, pair2 = decide_exchange_every(sweep_us, x1, x2, b1, b2, planes, H)
+    # every rank decided from the same reduced numbers; make sure of it before anybody allocates ghosts of a width the others do not expect
+    lo_hi = torch.tensor([float(every), -float(every)], dtype=torch.float64, device=cdev)
+    dist.all_reduce(lo_hi, op=dist.ReduceOp.MAX)
+    agreed = int(lo_hi[0]) == every and int(-lo_hi[1]) == every
+    if not agreed:
+        every = 1
     return every, {"interior_sweep_us": sweep_us, "exchange_H_planes_us": x1, "exchange_2H_planes_us": x2,
                    "boundary_launch_us_every1": b1, "boundary_launch_us_every2": b2,
-                   "pair_us_exchange_every_launch": pair1, "pair_us_one_exchange_per_pair": pair2, "chosen_every": every}
+                   "pair_us_exchange_every_launch": pair1, "pair_us_one_exchange_per_pair": pair2, "chosen_every": every,
+                   "ranks_agreed": bool(agreed), "this_rank": mine}
 
 
 def _write_view_stc(base_stc, ndim, L_view, cache_dir, tag):
@@ -443,6 +472,62 @@ class SlabRun:
             if self.world > 1:
                 self._exchange(dst)
         self.launch_count += 1
+
+    def timeline(self, pairs=4):
+        """What one exchanging launch is made of on THIS rank, in microseconds averaged over `pairs` ping-pong pairs of the run's own loop
+        (collective: every rank calls it with the same count): the boundary launch, the interior sweep, the halo exchange on the side
+        stream (from the moment the boundary planes exist), and how long the main stream then still waits for the ghosts -- 0 when the
+        exchange hides under the interior sweep.  every = 2: also the whole-slab launch that has no exchange beside it."""
+        if not (self.gpu and self.world > 1):
+            return None
+        torch, p, H = self.torch, self.plan, self.H
+        a, b = p.interior
+        E = lambda: torch.cuda.Event(enable_timing=True)
+        acc = {"boundary_us": 0.0, "interior_us": 0.0, "exchange_us": 0.0, "wait_for_ghosts_us": 0.0, "exchanging_launch_us": 0.0, "whole_slab_launch_us": 0.0}
+        n_x = n_l = 0
+        sh = self.main.cuda_stream
+        for _ in range(pairs):
+            for src, dst, local in ((self.A, self.B, p.every == 2), (self.B, self.A, False)):
+                e = [E() for _ in range(6)]
+                e[0].record(self.main)
+                if local:
+                    self.launch_local(src, dst)
+                    e[1].record(self.main)
+                    torch.cuda.synchronize(self.device)
+                    acc["whole_slab_launch_us"] += e[0].elapsed_time(e[1]) * 1e3
+                    n_l += 1
+                    continue
+                if p.pair_view() and hasattr(self.sweep, "pair"):
+                    self.sweep.pair(src[p.top[0]:p.top[1]], dst[p.top[0]:p.top[1]], src[p.bot[0]:p.bot[1]], dst[p.bot[0]:p.bot[1]], sh)
+                else:
+                    for v in (p.top, p.bot):
+                        if v is not None:
+                            self.sweep(src[v[0]:v[1]], dst[v[0]:v[1]], sh)
+                e[1].record(self.main)
+                self.ev_b.record(self.main)
+                if b - a > 2 * H:
+                    self.sweep(src[a:b], dst[a:b], sh)
+                e[2].record(self.main)
+                with torch.cuda.stream(self.side):
+                    self.side.wait_event(self.ev_b)
+                    e[3].record(self.side)
+                    self._exchange(dst)
+                    e[4].record(self.side)
+                    self.ev_c.record(self.side)
+                self.main.wait_event(self.ev_c)
+                e[5].record(self.main)
+                self.launch_count += 1
+                torch.cuda.synchronize(self.device)
+                acc["boundary_us"] += e[0].elapsed_time(e[1]) * 1e3
+                acc["interior_us"] += e[1].elapsed_time(e[2]) * 1e3
+                acc["exchange_us"] += e[3].elapsed_time(e[4]) * 1e3
+                acc["wait_for_ghosts_us"] += e[2].elapsed_time(e[5]) * 1e3
+                acc["exchanging_launch_us"] += e[0].elapsed_time(e[5]) * 1e3
+                n_x += 1
+        out = {k: round(v / max(1, n_l if k == "whole_slab_launch_us" else n_x), 1) for k, v in acc.items()}
+        out["every"] = p.every
+        out["planes_held"] = p.Lloc
+        return out
 
     def launch_local(self, src, dst):
         """One launch src -> dst over the whole local slab, no exchange (first launch of a pair, every = 2)."""

@@ -5,7 +5,13 @@ Counterpart of the reference's benchmarks/<stencil>/getGpuMetrics.py:4-38 (which
 metrics out of prof/<name>.csv).  Here the per-configuration metrics are the ones that matter for a
 bandwidth-bound stencil on MI355X: kernel duration, HBM traffic from the FETCH_SIZE / WRITE_SIZE counters
 (FETCH_SIZE doubled: gfx950 reports half of a wide coalesced stream), achieved GB/s against the 8 TB/s
-roofline, launch geometry and register/LDS use.  `duration.log` gets the duration like the reference's."""
+roofline, launch geometry and register/LDS use.  `duration.log` gets the duration like the reference's.
+
+Round 4: the "why" columns beside each winner (compile_run.sh's tcc / sq / sq2 / grbm passes), one counterpart per family of the reference's
+row: L2 Hit Rate (its "L2 Hit Rate"), Effective Clock (its "SM Frequency": GRBM_GUI_ACTIVE / 8 XCDs / the dispatch's own duration),
+Waves Waiting and Issue Stalled (its "No Eligible" / "Warp Cycles Per Issued Instruction"), Issue Busy ("Issue Slots Busy"), LDS Bank
+Conflicts ("Mem Pipes Busy" has no closer twin), the instruction mix ("Executed Instructions", "Branch Instructions"), VALU Busy ("SM Busy"),
+Waves and Occupancy ("Waves Per SM", "Theoretical Occupancy").  A pass that did not run leaves its cells empty."""
 import csv
 import glob
 import os
@@ -13,8 +19,15 @@ import re
 import sys
 
 HEADER = ["Metric Name", "Duration", "Calls", "FETCH_SIZE", "WRITE_SIZE", "HBM Traffic", "Algorithmic Bytes", "Achieved Bandwidth",
-          "Roofline Fraction", "GStencil/s", "Grid Size", "Block Size", "LDS Per Block", "VGPR", "SGPR", "Program Time", "RMS Error", "AGPR", "Scratch", "VGPR Spill"]
-UNITS = ["", "nsecond", "", "KiB", "KiB", "byte", "byte", "GB/s", "of 8 TB/s", "", "", "", "byte", "", "", "ms", "", "", "byte/lane", ""]
+          "Roofline Fraction", "GStencil/s", "Grid Size", "Block Size", "LDS Per Block", "VGPR", "SGPR", "Program Time", "RMS Error", "AGPR", "Scratch", "VGPR Spill",
+          # round 4: why it is as fast as it is
+          "Traffic / Algorithmic", "L2 Hit Rate", "Effective Clock", "Waves Waiting", "Issue Stalled", "Issue Busy", "LDS Bank Conflicts", "VALU Busy",
+          "VALU Instructions", "VMEM Read Instructions", "VMEM Write Instructions", "LDS Instructions", "SALU Instructions", "Branch Instructions",
+          "Waves", "Occupancy"]
+UNITS = ["", "nsecond", "", "KiB", "KiB", "byte", "byte", "GB/s", "of 8 TB/s", "", "", "", "byte", "", "", "ms", "", "", "byte/lane", "",
+         "", "of L2 requests", "GHz", "of wave cycles", "of wave cycles", "of wave cycles", "of LDS cycles", "of wave cycles",
+         "wave instructions", "wave instructions", "wave instructions", "wave instructions", "wave instructions", "wave instructions",
+         "", "waves/SIMD"]
 
 
 def _one(pattern):
@@ -35,13 +48,18 @@ def main(name=""):
     calls = int(stats[0]["Calls"]) if stats else 0
     vals = {}
     meta = {}
-    for key in ("fetch", "write"):
+    clock = float("nan")
+    for key in ("fetch", "write", "tcc", "sq", "sq2", "grbm"):
         rows = _dr_rows(_one(os.path.join(base, key, "**", "*_counter_collection.csv")))
         if rows:
-            meta = rows[0]
+            meta = meta or rows[0]
             for cname in set(r["Counter_Name"] for r in rows):
                 v = [float(r["Counter_Value"]) for r in rows if r["Counter_Name"] == cname]
                 vals[cname] = sum(v) / len(v)
+            if key == "grbm":       # busy cycles over the SAME dispatch's duration (the counter sums the 8 XCDs)
+                c = [float(r["Counter_Value"]) / 8.0 / max(1, int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) for r in rows
+                     if r["Counter_Name"] == "GRBM_GUI_ACTIVE" and "End_Timestamp" in r]
+                clock = sum(c) / len(c) if c else clock
     src = open(os.path.join("cu", name + ".hip")).read() if os.path.exists(os.path.join("cu", name + ".hip")) else ""
     mac = {m.group(1): int(m.group(2)) for m in re.finditer(r"^#define (L|M|N|Halo|Step) (-?\d+)", src, re.M)}
     esz = 4 if "typedef float real_t" in src else 8
@@ -64,9 +82,18 @@ def main(name=""):
     def _rep(label):
         m = re.search(re.escape(label) + r"\s*(\d+)", rep)
         return m.group(1) if m else ""
+    def ratio(a, b):
+        return vals[a] / vals[b] if a in vals and b in vals and vals[b] else ""
+    occ = re.search(r"Occupancy \[waves/SIMD\]:\s*(\d+)", rep)
+    why = [traffic / alg if alg and traffic == traffic else "",
+           vals["TCC_HIT_sum"] / (vals["TCC_HIT_sum"] + vals["TCC_MISS_sum"]) if "TCC_HIT_sum" in vals and (vals["TCC_HIT_sum"] + vals.get("TCC_MISS_sum", 0)) else "",
+           clock if clock == clock else "", ratio("SQ_WAIT_ANY", "SQ_WAVE_CYCLES"), ratio("SQ_WAIT_INST_ANY", "SQ_WAVE_CYCLES"), ratio("SQ_ACTIVE_INST_ANY", "SQ_WAVE_CYCLES"),
+           ratio("SQ_LDS_BANK_CONFLICT", "SQ_LDS_IDX_ACTIVE"), (vals["SQ_ACTIVE_INST_VALU"] / vals["SQ_WAVE_CYCLES"]) if "SQ_ACTIVE_INST_VALU" in vals and vals.get("SQ_WAVE_CYCLES") else "",
+           vals.get("SQ_INSTS_VALU", ""), vals.get("SQ_INSTS_VMEM_RD", ""), vals.get("SQ_INSTS_VMEM_WR", ""), vals.get("SQ_INSTS_LDS", ""), vals.get("SQ_INSTS_SALU", ""),
+           vals.get("SQ_INSTS_BRANCH", ""), vals.get("SQ_WAVES", ""), occ.group(1) if occ else ""]
     row = [name, dur, calls, fetch, write, traffic, alg, gbs, gbs / 8000.0, interior * mac.get("Step", 1) / dur if dur == dur and dur > 0 else float("nan"),
            meta.get("Grid_Size", ""), meta.get("Workgroup_Size", ""), meta.get("LDS_Block_Size", ""), meta.get("VGPR_Count", ""), meta.get("SGPR_Count", ""),
-           t.group(1) if t else "", rms.group(1) if rms else "", _rep("AGPRs:"), _rep("ScratchSize [bytes/lane]:"), _rep("VGPRs Spill:")]
+           t.group(1) if t else "", rms.group(1) if rms else "", _rep("AGPRs:"), _rep("ScratchSize [bytes/lane]:"), _rep("VGPRs Spill:")] + why
     new = not os.path.exists("gpuMetrics.csv")
     with open("gpuMetrics.csv", "a", newline="") as f:
         w = csv.writer(f, quoting=csv.QUOTE_ALL)

@@ -560,6 +560,41 @@ def searchSpace(stc, is3d, dtype, configs, outdir, iterations=8, budget_s=None, 
     return results
 
 
+NAMING_OPTIONS = {"--3d": 0, "--streaming": 0, "--dtype": 1, "--step": 1, "--temporal": 1, "--dist": 1}     # option -> values it takes
+
+
+def write_defaults(stc, is3d, dtype, results, source, table=None):
+    """The end of the loop the reference leaves to the user (benchmarks/3d7pt_star/tuning.py:125-131: the best configuration ends up in
+    duration.log and is copied into a command line by hand): for every (step, temporal, streaming) class present in `results`
+    (searchSpace's records or a results.jsonl), the fastest configuration that was compared with the gold kernel becomes the row of
+    drstencil_amd/tuned_defaults.tsv for this stencil shape, dtype and grid size -- the generator then emits it when `drstencil`
+    is given no geometry option, and bench.py's TUNED lists come from the same rows.  Returns the rows written."""
+    from drstencil_amd import tuned_defaults as td
+    best = {}
+    for r in results:
+        if "duration_ns" not in r or not r.get("verified"):
+            continue
+        a = r["args"].split()
+        cls = (int(r["step"]), 1 if r.get("arithmetic") == "reassociated" else 0, "--streaming" in a)
+        if cls not in best or r["GStencil"] > best[cls]["GStencil"]:
+            best[cls] = r
+    written = []
+    for (step, temporal, streaming), r in sorted(best.items()):
+        a, opts, i = r["args"].split(), [], 0
+        while i < len(a):
+            if a[i] in NAMING_OPTIONS:
+                i += 1 + NAMING_OPTIONS[a[i]]
+                continue
+            opts.append(a[i])
+            i += 1
+        mode, shape, points, order_, N = td.key_of(stc, 3 if is3d else 2, streaming)
+        row = dict(mode=mode, shape=shape, points=points, order=order_, step=step, dtype=dtype, temporal=temporal, N=N, options=" ".join(opts),
+                   source="%s (%s: %.0f ns, %.1f GStencil/s)" % (source, r["name"], r["duration_ns"], r["GStencil"]))
+        td.put(row, **({"path": table} if table else {}))
+        written.append(row)
+    return written
+
+
 def main():
     global order, ndim, elem_bytes
     ap = argparse.ArgumentParser(description="tuning-space search for one stencil on the local MI355X")
@@ -581,8 +616,17 @@ def main():
     ap.add_argument("--placement", default=None, choices=["measured", "kernel"],
                     help="3D grids with planes of 2 MiB or more: time every configuration at four positions of the output array and keep its best (measured, "
                          "default) or only at the kernel's recommended position (kernel); also DRS_TUNE_PLACEMENT")
+    ap.add_argument("--write-defaults", action="store_true",
+                    help="after the search: the fastest verified configuration per (step, temporal, streaming) class becomes this stencil's row of "
+                         "drstencil_amd/tuned_defaults.tsv (+ csrc/tuned_defaults.hpp; rebuild with make): the generator's defaults and bench.py's TUNED")
+    ap.add_argument("--from-results", default=None, help="with --write-defaults: no search, take the records of this results.jsonl")
     a = ap.parse_args()
     order, ndim, elem_bytes = a.order, (3 if a.is3d else 2), (4 if a.dtype == "fp32" else 8)
+    if a.write_defaults and a.from_results:
+        recs = [json.loads(l) for l in open(a.from_results) if l.strip()]
+        for row in write_defaults(os.path.abspath(a.stc), a.is3d, a.dtype, recs, a.from_results):
+            print("tuned default:", row["mode"], row["shape"], "step", row["step"], row["dtype"], "N", row["N"], "|", row["options"])
+        return
     if a.configs_file:
         paras = [l.strip() for l in open(a.configs_file) if l.strip() and not l.startswith("#")]
     else:
@@ -600,6 +644,9 @@ def main():
         os.environ["DRS_TUNE_PLACEMENT"] = a.placement
     res = searchSpace(os.path.abspath(a.stc), a.is3d, a.dtype, paras, a.out, budget_s=a.budget or None, jobs=a.jobs, profile_top=a.profile_top,
                       extra_opts=a.extra.split())
+    if a.write_defaults:
+        for row in write_defaults(os.path.abspath(a.stc), a.is3d, a.dtype, res, os.path.join(a.out, "results.jsonl")):
+            print("tuned default:", row["mode"], row["shape"], "step", row["step"], row["dtype"], "N", row["N"], "|", row["options"])
     print("best:")
     for r in res[:10]:
         print("  {name}  {duration_ns:.0f} ns  {GBps:.0f} GB/s  {GStencil:.1f} GStencil/s  verified vs gold: {verified}  arithmetic: {arithmetic}".format(**r))

@@ -113,7 +113,9 @@ int drs_kernel_run_timed(drs_kernel *k, void *d_a, void *d_b, int iterations, in
  * every = 1: each launch exchanges its output's H = step * order boundary planes with the <= 2 neighbours; every = 2: ghost
  * planes 2H wide, one exchange per ping-pong pair.  A pair is captured once into a HIP graph per (A, B) and replayed
  * (DRS_SLAB_GRAPH=0: eager); drs_slab_info tells ("graph": 1 captured, -1 refused -> eager).  rehearse_world > 0 plays rank
- * `rank` of `rehearse_world` on ONE GPU with itself as both neighbours (communicator of size 1): tests and one-GPU rehearsals. */
+ * `rank` of `rehearse_world` on ONE GPU with itself as both neighbours (communicator of size 1): tests and one-GPU rehearsals.
+ * drs_slab_run answers -1 on an error (drs_slab_error) and -3, like drs_kernel_run, when the slab was opened with `--temporal 1`
+ * options (on-chip stages, reassociated arithmetic) and `iterations` exceeds the kernels' tolerance horizon. */
 typedef struct drs_slab drs_slab;
 #define DRS_SLAB_ID_BYTES 128
 int drs_slab_unique_id(void *id128);

@@ -62,6 +62,11 @@ def main():
         for j, (ok, info) in zip(jobs, res):
             if not ok:
                 print(j[0], "BUILD FAILED", info.splitlines()[-1] if info else "", flush=True)
+            else:       # what the compiler allocated (cache hit: the stored report), beside what the generator names
+                k = drs.Kernel(j[4])
+                r, i = k.resources, k.info
+                print("%-32s vgprs %3s agprs %3s scratch %s occ %s lds %6d  named %3d  %d lanes, grid %d, %s" % (j[0], r.get("vgprs"), r.get("agprs"), r.get("scratch_bytes_per_lane"),
+                      r.get("occupancy_waves_per_simd"), i["lds_bytes"], i["reg_demand"], i["threads"], i["grid"], i.get("arithmetic")), flush=True)
         return
     kerns = []
     for j, (ok, info) in zip(jobs, res):

@@ -37,6 +37,13 @@ _add("3d_ahead_fp64_step2_reuse", 3, "t3_ahead", "--dtype", "fp64", "--sn", "8",
 _add("3d_ahead_fp64_window_dma", 3, "t3_ahead", "--dtype", "fp64", "--sn", "8", "--schedule", "window", "--stage", "dma")
 _add("3d7_fp32_eager", 3, "t3_star", "--dtype", "fp32", "--lazy-rims", "0", "--prefetch")
 _add("3d7_fp32_cyclicy", 3, "t3_star", "--dtype", "fp32", "--cyclic-merge-y", "3", "--by", "2", "--bx", "32", "--sn", "9")
+_add("3d7_fp32_step2_xcd_units", 3, "t3_star", "--dtype", "fp32", "--step", "2", "--sn", "8", "--xcd-remap", "4", "--bx", "16", "--by", "4", "--block-merge-y", "2")
+_add("3d7_fp64_t3_skew", 3, "t3_star", "--dtype", "fp64", "--step", "3", "--temporal", "1", "--skew", "1", "--pin", "1", "--exact-y", "1", "--bx", "34", "--by", "8", "--block-merge-y", "2", "--sn", "16", "--xcd-remap", "4")
+_add("3d7_fp32_t2_skew_rows", 3, "t3_star", "--dtype", "fp32", "--step", "2", "--temporal", "1", "--skew", "1", "--order", "rows", "--prefetch", "--bx", "34", "--by", "8", "--block-merge-y", "2", "--sn", "16")
+# round 4: --cyclic-merge-x is the reference's strided layout (a lane's points Bx columns apart; codegen.hpp:116-141)
+_add("3d7_fp32_cyclicx", 3, "t3_star", "--dtype", "fp32", "--cyclic-merge-x", "4", "--bx", "32", "--by", "4", "--block-merge-y", "2", "--sn", "9")
+_add("3d7_fp64_cyclicx_step2", 3, "t3_star", "--dtype", "fp64", "--step", "2", "--cyclic-merge-x", "2", "--bx", "64", "--by", "4", "--block-merge-y", "2", "--sn", "8", "--prefetch")
+_add("2d25_fp64_cyclicx_tile", 2, "t2_box25", "--dtype", "fp64", "--cyclic-merge-x", "4", "--bx", "32", "--by", "4", "--block-merge-y", "2")
 _add("3d7_fp32_bx128", 3, "t3_star", "--dtype", "fp32", "--bx", "128", "--by", "2", "--block-merge-y", "2", "--xrim", "dpp")
 _add("3d7_fp32_refdefaults", 3, "t3_star", "--dtype", "fp32", "--ref-defaults")
 _add("3d7_fp32_nt", 3, "t3_star", "--dtype", "fp32", "--nt-store", "1", "--nt-load", "1", "--xcd-remap", "0")

@@ -208,3 +208,62 @@ def test_temporal_kernel_refuses_iterations_beyond_its_horizon():
         kern.run(0, 0, iterations=kern.info["tolerance_horizon_iterations"] + 1)
     with pytest.raises(drs.ToleranceHorizonExceeded):
         kern.run_timed(0, 0, iterations=100)
+
+
+def test_tuned_defaults_table_feeds_generator_and_bench(tmp_path):
+    """The tuner -> generator loop (reference: benchmarks/3d7pt_star/tuning.py:125-131 leaves the winner in duration.log): the table
+    drstencil_amd/tuned_defaults.tsv, its generated C++ twin, the generator's behaviour without geometry options and bench.py's TUNED
+    lists all say the same thing."""
+    import bench
+    import drstencil_amd as drs
+    from drstencil_amd import tuned_defaults as td
+    rows = td.load()
+    assert td.header_text(rows) == open(td.HEADER).read(), "csrc/tuned_defaults.hpp is stale: python3 -m drstencil_amd.tuned_defaults; make -C drstencil_amd/csrc"
+    body = lambda src: src[src.index("#include"):]
+    for w in ("c4", "c3", "c4f64", "c5", "c2", "s_2d25pt_box", "s_2d5pt_cross", "s_3d9pt_cross"):
+        wl, h = bench.WORKLOADS[w], bench.HEADLINE[w]
+        naming = td.problem_options(wl["ndim"], wl["dtype"], **h)
+        assert bench.TUNED[w][:len(naming)] == naming and len(bench.TUNED[w]) > len(naming)
+        rc0, msg0, bare = drs.generate(naming + [wl["stc"]])
+        rc1, msg1, full = drs.generate(bench.TUNED[w] + [wl["stc"]])
+        assert rc0 == rc1 == 0 and body(bare) == body(full), w
+        assert "the tuner's configuration" in msg0 and "the tuner's configuration" not in msg1
+        rc2, _, generic = drs.generate(naming + ["--tuned-defaults", "0", wl["stc"]])
+        assert rc2 == 0 and (body(generic) != body(full) or w not in ("c4", "c4f64")), w      # (several winners ARE the generic geometry; C4's is not)
+    # any geometry option of the user's switches the table off; --ref-defaults too
+    stc4 = bench.WORKLOADS["c4"]["stc"]
+    _, m, s_sn = drs.generate(["--3d", "--dtype", "fp32", "--step", "2", "--sn", "16", stc4])
+    assert "the tuner's configuration" not in m and "#define Bx 32\n" in s_sn
+    # a size far from every row (256^3) keeps the generic defaults; 1000^3 is within sqrt 2 of the 1024 row
+    from helpers import write_stc
+    star = [(0, 0, 0, 0.3), (1, 0, 0, 0.2), (-1, 0, 0, 0.2), (0, 1, 0, 0.2), (0, -1, 0, 0.2), (0, 0, 1, 0.2), (0, 0, -1, 0.2)]
+    small, near = str(tmp_path / "s256.stc"), str(tmp_path / "s1000.stc")
+    write_stc(small, 3, (256, 256, 256), 4, star)
+    write_stc(near, 3, (1000, 1000, 1000), 4, star)
+    assert "the tuner's configuration" not in drs.generate(["--3d", "--dtype", "fp32", "--step", "2", small])[1]
+    assert "--bx 64 --by 16" in drs.generate(["--3d", "--dtype", "fp32", "--step", "2", near])[1]
+
+
+def test_tuner_writes_the_defaults_table(tmp_path):
+    """tuning.py --write-defaults: the fastest VERIFIED record per (step, temporal, streaming) class becomes the row; naming options are
+    stripped; an existing row of the same class and size is replaced, others stay."""
+    import shutil
+    import bench
+    from drstencil_amd import tuned_defaults as td
+    from drstencil_amd.tuner import tuning as t
+    table = str(tmp_path / "t.tsv")
+    shutil.copy(td.TABLE, table)
+    before = td.load(table)
+    stc4 = bench.WORKLOADS["c4"]["stc"]
+    recs = [dict(name="a", args="--3d --dtype fp32 --step 2 --bx 32 --by 16 --sn 32", duration_ns=1500.0, GStencil=1400.0, step=2, arithmetic="gold-order", verified=True),
+            dict(name="b", args="--3d --dtype fp32 --step 2 --bx 64 --by 8 --sn 8 --pin 1", duration_ns=1400.0, GStencil=1500.0, step=2, arithmetic="gold-order", verified=True),
+            dict(name="wrong", args="--3d --dtype fp32 --step 2 --bx 16 --by 16", duration_ns=100.0, GStencil=9999.0, step=2, arithmetic="gold-order", verified=False),
+            dict(name="t", args="--3d --dtype fp32 --step 2 --temporal 1 --bx 66 --by 15", duration_ns=1450.0, GStencil=1450.0, step=2, arithmetic="reassociated", verified=True)]
+    rows = t.write_defaults(stc4, True, "fp32", recs, "unit test", table=table)
+    assert sorted((r["temporal"], r["options"]) for r in rows) == [(0, "--bx 64 --by 8 --sn 8 --pin 1"), (1, "--bx 66 --by 15")]
+    after = td.load(table)
+    assert len(after) == len(before) + 1          # the fused row replaced c4's, the temporal row is new
+    mode, shape, points, order, N = td.key_of(stc4, 3)
+    assert td.lookup(mode, shape, 2, "fp32", 0, N, after) == "--bx 64 --by 8 --sn 8 --pin 1".split()
+    assert td.lookup(mode, shape, 2, "fp32", 1, N, after) == ["--bx", "66", "--by", "15"]
+    assert td.lookup(mode, shape, 2, "fp64", 0, N, after) == td.lookup(mode, shape, 2, "fp64", 0, N, before)

@@ -108,6 +108,21 @@ VARIANTS = [
     ("3d_defer_stores_reuse_dma", 3, "STAR3", (19, 23, 264), ["--3d", "--dtype", "fp32", "--sn", "5", "--step", "2", "--dist", "1", "--stage", "dma", "--defer-stores", "1"]),
     ("3d_defer_stores_window", 3, "STAR3", (19, 23, 262), ["--3d", "--dtype", "fp64", "--sn", "4", "--step", "2", "--schedule", "window", "--prefetch", "--defer-stores", "1", "--uniform-loads", "2"]),
     ("2d_stream_defer_stores", 2, "BOX25", (1, 61, 268), ["--dtype", "fp32", "--streaming", "--sn", "9", "--prefetch", "--defer-stores", "1"]),
+    # round 4: --xcd-remap 4 -- units of 32 consecutive tiles of one stream block dealt round-robin to the XCDs (ragged: 3 x 5 tiles, 3 blocks)
+    ("3d_xcd_units_s2", 3, "STAR3", (23, 37, 300), ["--3d", "--dtype", "fp32", "--sn", "7", "--step", "2", "--prefetch", "--xcd-remap", "4", "--bx", "32", "--by", "4", "--block-merge-y", "2"]),
+    ("3d_xcd_units_many_tiles", 3, "STAR3", (12, 70, 530), ["--3d", "--dtype", "fp64", "--sn", "5", "--xcd-remap", "4", "--bx", "16", "--by", "2", "--block-merge-y", "2"]),
+    ("2d_stream_xcd_units", 2, "BOX25", (1, 61, 1068), ["--dtype", "fp32", "--streaming", "--sn", "9", "--xcd-remap", "4", "--bx", "16"]),
+    # round 4: --cyclic-merge-x is the reference's strided layout (codegen.hpp:116-141, `mi += blockDim.x`): a lane's points are Bx columns
+    # apart, element-wide accesses, the x rim by DPP from the neighbouring lane's point of the same index
+    ("3d_cyclicx_fp32", 3, "STAR3", (12, 17, 263), ["--3d", "--dtype", "fp32", "--sn", "5", "--cyclic-merge-x", "4", "--bx", "32", "--by", "4", "--block-merge-y", "2"]),
+    ("3d_cyclicx_s2_prefetch_fp64", 3, "STAR3", (17, 21, 300), ["--3d", "--dtype", "fp64", "--sn", "6", "--step", "2", "--prefetch", "--cyclic-merge-x", "2", "--bx", "64", "--by", "4", "--block-merge-y", "2"]),
+    ("3d_cyclicx_cyclicy_lds", 3, "STAR3", (15, 29, 140), ["--3d", "--dtype", "fp32", "--sn", "5", "--cyclic-merge-x", "3", "--cyclic-merge-y", "3", "--by", "2", "--bx", "16", "--xrim", "lds"]),
+    ("3d_cyclicx_reuse_dist1", 3, "STAR3", (19, 23, 262), ["--3d", "--dtype", "fp32", "--sn", "7", "--step", "2", "--dist", "1", "--cyclic-merge-x", "2", "--bx", "32", "--by", "4"]),
+    ("3d_cyclicx_window_buffer_stores", 3, "STAR3", (19, 23, 262), ["--3d", "--dtype", "fp64", "--sn", "4", "--step", "2", "--schedule", "window", "--cyclic-merge-x", "2", "--bx", "32", "--by", "8", "--store-mask", "buffer"]),
+    ("3d_cross_cyclicx", 3, "CROSS3", (14, 19, 136), ["--3d", "--dtype", "fp64", "--dist", "2", "--step", "2", "--cyclic-merge-x", "2", "--bx", "32", "--by", "8", "--block-merge-y", "2"]),
+    ("2d25_tile_cyclicx", 2, "BOX25", (1, 61, 268), ["--dtype", "fp64", "--cyclic-merge-x", "4", "--bx", "32", "--by", "4", "--block-merge-y", "2"]),
+    ("2d25_stream_cyclicx_s2", 2, "BOX25", (1, 61, 268), ["--dtype", "fp32", "--streaming", "--sn", "9", "--step", "2", "--prefetch", "--cyclic-merge-x", "2", "--bx", "64"]),
+    ("2d_refdefaults_cyclicx", 2, "BOX9", (1, 41, 70), ["--dtype", "fp64", "--ref-defaults", "--cyclic-merge-x", "2"]),
 ]
 
 # --stage dma: planes staged by LDS-DMA into the per-lane-dense LDS image (own region [row][vector][lane], halo pieces by loader task);
@@ -187,6 +202,14 @@ EDGE = [
     ("2d_temporal2_tile_small", 2, "BOX9", (1, 7, 9), ["--dtype", "fp64", "--step", "2", "--temporal", "1"]),
     ("2d_oddN_box25_stream", 2, "BOX25", (1, 23, 31), ["--dtype", "fp64", "--streaming", "--sn", "4", "--xrim", "lds"]),
     ("3d_temporal2_prefetch_depth2", 3, "STAR3", (17, 21, 300), ["--3d", "--dtype", "fp64", "--sn", "6", "--step", "2", "--temporal", "1", "--prefetch", "--prefetch-depth", "2", "--by", "8", "--block-merge-y", "2"]),
+    ("3d_cyclicx_temporal2_fwd", 3, "STAR3", (17, 21, 300), ["--3d", "--dtype", "fp64", "--sn", "6", "--step", "2", "--temporal", "1", "--cyclic-merge-x", "4", "--bx", "32", "--by", "6", "--block-merge-y", "2"]),
+    ("3d_temporal3_skew_rows_fwd", 3, "STAR3", (15, 19, 140), ["--3d", "--dtype", "fp64", "--sn", "4", "--step", "3", "--temporal", "1", "--skew", "1", "--prefetch", "--order", "rows", "--exact-y", "1", "--bx", "34", "--by", "8", "--block-merge-y", "2"]),
+    ("3d_temporal2_skew_taps_pd2_fwd", 3, "STAR3", (17, 21, 300), ["--3d", "--dtype", "fp64", "--sn", "6", "--step", "2", "--temporal", "1", "--skew", "1", "--prefetch", "--prefetch-depth", "2", "--by", "8", "--block-merge-y", "2"]),
+    ("3d_temporal3_skew_ragged_fwd", 3, "STAR3", (13, 17, 70), ["--3d", "--dtype", "fp64", "--step", "3", "--temporal", "1", "--skew", "1", "--bx", "18", "--by", "8", "--block-merge-y", "2", "--sn", "2", "--prefetch"]),
+    ("2d_stream_temporal4_skew_fwd", 2, "STAR2", (1, 40, 270), ["--dtype", "fp64", "--streaming", "--sn", "7", "--step", "4", "--temporal", "1", "--skew", "1", "--prefetch"]),
+    ("3d_temporal3_skew2_taps_fwd", 3, "STAR3", (15, 19, 140), ["--3d", "--dtype", "fp64", "--sn", "4", "--step", "3", "--temporal", "1", "--skew", "2", "--prefetch", "--pin", "1", "--exact-y", "1", "--bx", "34", "--by", "8", "--block-merge-y", "2"]),
+    ("3d_temporal3_skew2_sn1_fwd", 3, "STAR3", (13, 17, 70), ["--3d", "--dtype", "fp64", "--step", "3", "--temporal", "1", "--skew", "2", "--bx", "18", "--by", "8", "--block-merge-y", "2", "--sn", "1", "--prefetch"]),
+    ("2d_stream_temporal4_skew2_fwd", 2, "STAR2", (1, 40, 270), ["--dtype", "fp64", "--streaming", "--sn", "7", "--step", "4", "--temporal", "1", "--skew", "2", "--prefetch", "--order", "rows"]),
     ("3d_temporal2_window_loads", 3, "STAR3", (17, 21, 300), ["--3d", "--dtype", "fp64", "--sn", "6", "--step", "2", "--temporal", "1", "--prefetch", "--prefetch-depth", "2", "--by", "8", "--block-merge-y", "2", "--uniform-loads", "2", "--drain", "1"]),
 ]
 
@@ -218,6 +241,18 @@ def test_emulated_edge_geometries(vid, ndim, pts, dims, opts, tmp_path):
 
 RACE = [
     ("3d_temporal2_prefetch", 3, "STAR3", (17, 21, 300), ["--3d", "--dtype", "fp64", "--sn", "6", "--step", "2", "--temporal", "1", "--prefetch", "--by", "8", "--block-merge-y", "2"]),
+    ("3d_cyclicx_temporal2", 3, "STAR3", (17, 21, 300), ["--3d", "--dtype", "fp64", "--sn", "6", "--step", "2", "--temporal", "1", "--cyclic-merge-x", "4", "--bx", "32", "--by", "6", "--block-merge-y", "2"]),
+    # round 4: --skew 1 -- stage t consumes what stage t-1 completed one iteration earlier; two barriers per iteration for all stages
+    ("3d_temporal3_skew_rows", 3, "STAR3", (15, 19, 140), ["--3d", "--dtype", "fp64", "--sn", "4", "--step", "3", "--temporal", "1", "--skew", "1", "--prefetch", "--order", "rows", "--exact-y", "1", "--bx", "34", "--by", "8", "--block-merge-y", "2"]),
+    ("3d_temporal2_skew_taps_pd2", 3, "STAR3", (17, 21, 300), ["--3d", "--dtype", "fp64", "--sn", "6", "--step", "2", "--temporal", "1", "--skew", "1", "--prefetch", "--prefetch-depth", "2", "--xrim", "lds", "--by", "8", "--block-merge-y", "2"]),
+    ("3d_temporal3_skew_sn1", 3, "STAR3", (13, 17, 70), ["--3d", "--dtype", "fp64", "--step", "3", "--temporal", "1", "--skew", "1", "--bx", "18", "--by", "8", "--block-merge-y", "2", "--sn", "1", "--prefetch", "--pin", "1"]),
+    ("2d_stream_temporal4_skew", 2, "STAR2", (1, 40, 270), ["--dtype", "fp64", "--streaming", "--sn", "7", "--step", "4", "--temporal", "1", "--skew", "1", "--prefetch", "--order", "rows"]),
+    ("2d25_stream_temporal2_skew", 2, "BOX25", (1, 61, 268), ["--dtype", "fp64", "--streaming", "--sn", "9", "--step", "2", "--temporal", "1", "--skew", "1", "--prefetch", "--xrim", "lds"]),
+    ("3d_temporal3_skew2_taps", 3, "STAR3", (15, 19, 140), ["--3d", "--dtype", "fp64", "--sn", "4", "--step", "3", "--temporal", "1", "--skew", "2", "--prefetch", "--pin", "1", "--exact-y", "1", "--bx", "34", "--by", "8", "--block-merge-y", "2"]),
+    ("3d_temporal3_skew2_rows", 3, "STAR3", (17, 21, 300), ["--3d", "--dtype", "fp64", "--sn", "6", "--step", "3", "--temporal", "1", "--skew", "2", "--prefetch", "--order", "rows", "--bx", "18", "--by", "8", "--block-merge-y", "2"]),
+    ("3d_temporal2_skew2_pd2_lds", 3, "STAR3", (17, 21, 300), ["--3d", "--dtype", "fp64", "--sn", "6", "--step", "2", "--temporal", "1", "--skew", "2", "--prefetch", "--prefetch-depth", "2", "--xrim", "lds", "--by", "8", "--block-merge-y", "2"]),
+    ("2d_stream_temporal4_skew2", 2, "STAR2", (1, 40, 270), ["--dtype", "fp64", "--streaming", "--sn", "7", "--step", "4", "--temporal", "1", "--skew", "2", "--prefetch"]),
+    ("2d25_stream_temporal2_skew2", 2, "BOX25", (1, 61, 268), ["--dtype", "fp64", "--streaming", "--sn", "9", "--step", "2", "--temporal", "1", "--skew", "2", "--prefetch", "--xrim", "lds"]),
     ("3d_temporal3_lds", 3, "STAR3", (15, 19, 140), ["--3d", "--dtype", "fp64", "--sn", "4", "--step", "3", "--temporal", "1", "--xrim", "lds", "--bx", "34", "--by", "8", "--block-merge-y", "2"]),
     ("3d_step1_window_lazy", 3, "STAR3", (15, 19, 300), ["--3d", "--dtype", "fp64", "--sn", "5", "--schedule", "window", "--lazy-rims", "1", "--xrim", "lds"]),
     ("3d_step1_scatter_prefetch", 3, "STAR3", (15, 19, 300), ["--3d", "--dtype", "fp64", "--sn", "5", "--prefetch", "--xrim", "lds"]),

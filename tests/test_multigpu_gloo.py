@@ -216,3 +216,62 @@ def test_bench_verifies_a_decomposed_run_without_a_global_reference(world, step,
         assert not any(r[1] for r in res) and not res[1][2]        # AND over the ranks; rank 1 itself saw the difference
     else:
         assert all(r[1] and r[2] for r in res)
+
+
+def test_exchange_decision_rule():
+    """decide_exchange_every on its own: a fast link takes one exchange per pair; a link too slow to hide 2H planes under one sweep, but
+    fast enough to hide H planes under each of two, flips to an exchange per launch; thin slabs never get wide ghosts."""
+    from drstencil_amd.multigpu import decide_exchange_every
+    assert decide_exchange_every(200.0, 40.0, 80.0, 20.0, 20.0, 128, 2)[0] == 2
+    assert decide_exchange_every(200.0, 150.0, 300.0, 20.0, 20.0, 128, 2)[0] == 1
+    assert decide_exchange_every(200.0, 400.0, 800.0, 20.0, 20.0, 128, 2)[0] == 1      # slower than the sweep either way: no redundant planes on top
+    assert decide_exchange_every(200.0, 1.0, 2.0, 20.0, 20.0, 12, 2)[0] == 1
+
+
+def _calib_worker(rank, world, port, us_per_plane, q):
+    """measure_exchange_every on CPU ranks over gloo: a `sweep` that takes 400 us per plane and a link that takes `us_per_plane` per plane
+    sent (the sleep is inside the exchange of THIS run's process group, i.e. where a slow xGMI link would show)."""
+    import time
+    sys.path.insert(0, ROOT)
+    import drstencil_amd.multigpu as mg
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    real = mg.batch_p2p
+
+    def slow_link(torch_, dist_, ops):
+        planes = max((t.shape[0] for k, t, _ in ops if k == "send"), default=0)
+        real(torch_, dist_, ops)
+        time.sleep(planes * us_per_plane * 1e-6)
+    mg.batch_p2p = slow_link
+
+    def sweep(src, dst, stream):
+        time.sleep(src.shape[0] * 400e-6)
+    every, m = mg.measure_exchange_every(torch, dist, (256, 8, 16), 2, rank, world, sweep, torch.device("cpu"), torch.float32, reps=3)
+    q.put((rank, every, m))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("us_per_plane,expected", [(50.0, 2), (30000.0, 1)])
+def test_slow_link_flips_the_exchange_mode(us_per_plane, expected):
+    """world 2 over gloo, 128 planes per rank, H = 2: an interior sweep takes ~50 ms (sleeps long enough to stand out of a loaded test
+    machine's noise).  A link at 50 us per plane hides 4 planes under it (one exchange per pair); at 30 ms per plane the 4-plane exchange
+    takes 120 ms and the 2-plane one 60 ms -- the calibration must flip to an exchange per launch, on every rank alike, and say that the
+    ranks agreed."""
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_calib_worker, args=(r, world, port, us_per_plane, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=180) for _ in range(world)), key=lambda r: r[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert [r[1] for r in res] == [expected] * world, res
+    for _, _, m in res:
+        assert m["ranks_agreed"] and m["chosen_every"] == expected and set(m["this_rank"]) >= {"interior_sweep_us", "exchange_H_planes_us", "exchange_2H_planes_us"}
+        assert m["exchange_H_planes_us"] > 0 and (expected == 2 or m["exchange_2H_planes_us"] > m["exchange_H_planes_us"])
+    assert res[0][2]["pair_us_one_exchange_per_pair"] == res[1][2]["pair_us_one_exchange_per_pair"]      # decided from the same reduced numbers
