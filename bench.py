@@ -114,10 +114,19 @@ TUNED = _tuned()
 STEP1 = {w: __import__("drstencil_amd.tuned_defaults", fromlist=["x"]).options_for(WORKLOADS[w]["stc"], 3, "fp32") for w in ("c4", "c3")}     # the table's step-1 rows
 # on-chip temporal blocking (two applications of the one-step stencil per launch; equal to the fused stencil up to
 # rounding, 6.8e-7 relative at full size): 66 lanes x 4 = 264 columns own 256, so 4 tiles cover N = 1024 exactly
-TEMPORAL2 = {
-    "c4": ["--3d", "--dtype", "fp32", "--step", "2", "--temporal", "1", "--prefetch", "--bx", "66", "--by", "15", "--block-merge-x", "4", "--block-merge-y", "2", "--sn", "32", "--xcd-remap", "0"],
-    "c3": ["--3d", "--dtype", "fp32", "--step", "2", "--temporal", "1", "--prefetch", "--bx", "66", "--by", "15", "--block-merge-x", "4", "--block-merge-y", "2", "--sn", "16", "--xcd-remap", "0"],
-}
+def _temporal(step, workloads):
+    from drstencil_amd import tuned_defaults as td
+    rows = td.load()
+    return {w: td.options_for(WORKLOADS[w]["stc"], WORKLOADS[w]["ndim"], WORKLOADS[w]["dtype"], step=step, temporal=1, rows=rows) for w in workloads}
+
+
+TEMPORAL2 = _temporal(2, ("c4", "c3"))
+# round 4: three on-chip stages in the reference's precision, where they pay: 21 fp64 FMAs per point instead of the fused stencil's 63.  The
+# SKEWED pipeline (--skew 1: stage t consumes what stage t-1 completed one iteration earlier, so an iteration's stages are independent and
+# share two barriers), exact source-plane halo (--exact-y 1), pinned sums, 256-plane blocks, XCD work units (--xcd-remap 4):
+# 3.21 ms per launch at 1024^3 = 986 GStencil/s against 868 for the fused --step 3 kernel and 730 for the step-2 headline
+# (profiles/r04_exp_r4b/d.log); 1.6e-15 from the fused arithmetic (bar 1e-12, tolerance horizon 112 386 iterations)
+TEMPORAL3 = _temporal(3, ("c4f64", "c3f64"))
 # round 2: the same fused stencil with rotating register windows instead of carried partial sums (--schedule window): 126 VGPRs with
 # -fno-slp-vectorize and --waves-per-eu 4, no scratch, so TWO 512-lane workgroups share a CU (one reads while the other writes) and 8-plane
 # stream blocks cost nothing: +0.8 % over the headline in interleaved runs on one box (profiles/r02_exp_r2j/k_*.log) -- a side measurement
@@ -200,6 +209,7 @@ def kernels():
     out += [("bench_%s_prev_headline" % w, w, PREV_HEADLINE[w]) for w in sorted(PREV_HEADLINE)]
     out += [("bench_%s_step1" % w, w, STEP1[w]) for w in sorted(STEP1)]
     out += [("bench_%s_temporal2" % w, w, TEMPORAL2[w]) for w in sorted(TEMPORAL2)]
+    out += [("bench_%s_temporal3" % w, w, TEMPORAL3[w]) for w in sorted(TEMPORAL3)]
     out += [("bench_%s_window_two_workgroups" % w, w, WINDOW2WG[w]) for w in sorted(WINDOW2WG)]
     out += [("bench_%s_fused3_%d" % (w, i), w, o) for w in sorted(FUSED3) for i, o in enumerate(FUSED3[w])]
     return out
@@ -223,6 +233,43 @@ def pmc_traffic(workload, option_string):
         return None, "no PMC passes committed for [%s][%s] in %s" % (workload, option_string, path)
 
 
+def oracle_check_slabs(workload, step, slabs, temporal):
+    """The checker half of the CPU leg: one oracle sweep per slab of the run's own input that verify_timed_kernel kept -- bottom of the grid,
+    across a stream-block / tile-row boundary in the middle, top of the grid (byte offsets beyond 2^32 at 1024^3) -- against what the
+    timed kernel wrote there in ONE launch: bit-exact, except temporal blocking (1e-6 relative fp32 / 1e-12 fp64)."""
+    import numpy as np
+    import oracle
+    w = WORKLOADS[workload]
+    spec = oracle.Spec(w["stc"], w["ndim"], step)
+    L, M, N = spec.dims
+    dt = np.float32 if w["dtype"] == "fp32" else np.float64
+    h = spec.halo
+    tol = 1e-6 if w["dtype"] == "fp32" else 1e-12
+    check = {"ok": True, "max_rel": 0.0, "bit_exact_required": not temporal, "slabs": []}
+    for sl in slabs:
+        sub = np.ascontiguousarray(sl["input"], dtype=dt)
+        nsl = sub.shape[0]
+        dst = np.zeros_like(sub)
+        cs = oracle.Spec(w["stc"], w["ndim"], step)
+        if w["ndim"] == 3:
+            cs.set_dims(nsl, M, N)
+        else:
+            cs.set_dims(1, nsl, N)
+        oracle.sweep(cs, sub, dst, contract=1)
+        ref, got = dst[h:nsl - h], sl["output"]
+        if temporal:
+            sel = (slice(None),) + tuple(slice(h, d - h) for d in ref.shape[1:])
+            rel = float(np.max(np.abs(got[sel].astype(np.float64) - ref[sel]) / np.maximum(np.abs(ref[sel]), 1e-30)))
+            ok = rel <= tol
+        else:
+            ok = bool(np.array_equal(got, ref))
+            rel = 0.0 if ok else float(np.max(np.abs(got.astype(np.float64) - ref) / np.maximum(np.abs(ref), 1e-30)))
+        check["slabs"].append({"position": sl["label"], "first_slice": int(sl["z0"]), "slices": int(nsl), "ok": bool(ok), "max_rel": rel})
+        check["ok"] = bool(check["ok"] and ok)
+        check["max_rel"] = max(check["max_rel"], rel)
+    return check
+
+
 def cpu_baseline(workload, step, budget_s=4.0, host_slab=None, gpu_first_launch=None, temporal=False):
     """The CPU leg (the only place bench.py touches oracle/): the oracle (port) timed on the host cores on a bounded z/y-slab
     sample of the workload -- the first slices of the very array the GPU loop started from (host_slab), or seeded random
@@ -241,34 +288,7 @@ def cpu_baseline(workload, step, budget_s=4.0, host_slab=None, gpu_first_launch=
     spec = oracle.Spec(w["stc"], w["ndim"], step)
     L, M, N = spec.dims
     dt = np.float32 if w["dtype"] == "fp32" else np.float64
-    check = None
-    if gpu_first_launch:
-        # the checker: one oracle sweep per slab of the run's own input -- bottom of the grid, across a stream-block / tile-row boundary
-        # in the middle, top of the grid (byte offsets beyond 2^32 at 1024^3) -- against what the timed kernel wrote there in ONE launch
-        h = spec.halo
-        tol = 1e-6 if w["dtype"] == "fp32" else 1e-12
-        check = {"ok": True, "max_rel": 0.0, "bit_exact_required": not temporal, "slabs": []}
-        for sl in gpu_first_launch:
-            sub = np.ascontiguousarray(sl["input"], dtype=dt)
-            nsl = sub.shape[0]
-            dst = np.zeros_like(sub)
-            cs = oracle.Spec(w["stc"], w["ndim"], step)
-            if w["ndim"] == 3:
-                cs.set_dims(nsl, M, N)
-            else:
-                cs.set_dims(1, nsl, N)
-            oracle.sweep(cs, sub, dst, contract=1)
-            ref, got = dst[h:nsl - h], sl["output"]
-            if temporal:
-                sel = (slice(None),) + tuple(slice(h, d - h) for d in ref.shape[1:])
-                rel = float(np.max(np.abs(got[sel].astype(np.float64) - ref[sel]) / np.maximum(np.abs(ref[sel]), 1e-30)))
-                ok = rel <= tol
-            else:
-                ok = bool(np.array_equal(got, ref))
-                rel = 0.0 if ok else float(np.max(np.abs(got.astype(np.float64) - ref) / np.maximum(np.abs(ref), 1e-30)))
-            check["slabs"].append({"position": sl["label"], "first_slice": int(sl["z0"]), "slices": int(nsl), "ok": bool(ok), "max_rel": rel})
-            check["ok"] = bool(check["ok"] and ok)
-            check["max_rel"] = max(check["max_rel"], rel)
+    check = oracle_check_slabs(workload, step, gpu_first_launch, temporal) if gpu_first_launch else None
     # bounded sample: a slab of the outermost dim (same plane size, same stencil, same dtype)
     if w["ndim"] == 3:
         Ls = min(L, 128)
@@ -551,13 +571,15 @@ def main(argv=None):
             L *= pworld
         else:
             M *= pworld
-    kern1 = kernf = kernw = kernp = None
+    kern1 = kernf = kernw = kernp = kernt3 = None
     kern3 = []
     if pworld == 1:
         kern = drs.Kernel(opts + [w["stc"]])
         if args.workload in STEP1 and not args.kernel_args and not args.headline_only:
             kern1 = drs.Kernel(STEP1[args.workload] + [w["stc"]])
             kernf = drs.Kernel(TEMPORAL2[args.workload] + [w["stc"]])
+        if args.workload in TEMPORAL3 and not args.kernel_args and not args.headline_only:
+            kernt3 = drs.Kernel(TEMPORAL3[args.workload] + [w["stc"]])
         if not args.kernel_args and not args.headline_only:
             for o3 in FUSED3.get(args.workload, []):
                 try:
@@ -661,7 +683,7 @@ def main(argv=None):
             kern.run(A.data_ptr(), B.data_ptr(), iterations=iters, stream=stream.cuda_stream)
         torch.cuda.synchronize()
         # a few milliseconds of launches do not bring the GPU to its steady clocks (C3: 221 us per launch right after 2 ms of
-        # warm-up, 193 us from then on -- scripts/c3_loop_probe.py): keep running untimed steps until MIN_WARM_S have gone by
+        # warm-up, 193 us from then on -- scripts/archive/c3_loop_probe.py): keep running untimed steps until MIN_WARM_S have gone by
         tw = time.perf_counter()
         while args.warmup > 0 and time.perf_counter() - tw < MIN_WARM_S:
             for _ in range(8):
@@ -671,7 +693,7 @@ def main(argv=None):
         # FINITE DATA in every timed launch.  The shipped coefficients sum to 1.5 (0.3 + 6 x 0.2), so the values grow 1.5 x per time step and
         # a float array started from U[0, 1) is all inf after ~218 time steps -- which the warm-up above has long passed.  inf / NaN operands
         # cost the VALU less power and the chip clocks higher on them: the VALU-dense fused step-3 kernel takes 1.80-1.87 ms on finite data
-        # and 1.53-1.60 once the arrays have overflowed (scripts/probe_cold2.py, profiles/r03_probe_cold2.log; the memory-bound step-2
+        # and 1.53-1.60 once the arrays have overflowed (scripts/archive/probe_cold2.py, profiles/r03_probe_cold2.log; the memory-bound step-2
         # headline: 1.50 either way).  So the input is restored from a pristine copy right before every timed loop, and a loop longer than
         # the overflow horizon is timed in chunks with the restore between them (outside the events).
         def reseed():
@@ -719,6 +741,19 @@ def main(argv=None):
         fused2 = side(kernf, TEMPORAL2[args.workload], 32) if kernf is not None else None
         window2 = side(kernw, WINDOW2WG[args.workload], 32) if kernw is not None else None
         prev_headline = side(kernp, PREV_HEADLINE[args.workload], 32) if kernp is not None else None
+        temporal3 = None
+        if kernt3 is not None:
+            temporal3 = side(kernt3, TEMPORAL3[args.workload], 24)
+            temporal3["vgprs"], temporal3["lds_bytes"], temporal3["stages"] = kernt3.resources.get("vgprs"), kernt3.info["lds_bytes"], kernt3.info.get("stages")
+            temporal3["drift_estimate"] = kernt3.info.get("drift_estimate")
+            t3_traffic, t3_src = pmc_traffic(args.workload, " ".join(TEMPORAL3[args.workload]))
+            temporal3["traffic"], temporal3["traffic_source"] = t3_traffic, t3_src
+            if not args.no_verify:      # like the headline: one launch against the gold kernel on the whole grid (tolerance) + three oracle slabs (CPU leg)
+                g3 = torch.Generator(device=dev).manual_seed(1)
+                A.copy_(torch.rand(shape, dtype=tdt, device=dev, generator=g3))
+                t3_ok, t3_ver, _, t3_slabs = verify_timed_kernel(torch, kernt3, args.workload, A, B, True)
+                temporal3["verified"], temporal3["verification"] = t3_ok, t3_ver
+                temporal3["_slabs"] = t3_slabs
         fused3 = None
         if kern3:
             # every candidate timed on THIS device, on finite data (side() restores the pristine input first), the fastest reported in full
@@ -901,7 +936,7 @@ def main(argv=None):
         if args.slab_runtime == "native":
             calibration = dict(calibration or {}, native_runtime=run.slab.info)
         parallelism = "%s-slab x%d%s, RCCL send/recv halo every %d launch(es), overlapped" % ("z" if w["ndim"] == 3 else "y", pworld, " (weak: grid %s)" % "x".join(str(d) for d in ((L, M, N) if w["ndim"] == 3 else (M, N))) if weak else "", args.exchange_every)
-        step1 = fused2 = window2 = fused3 = prev_headline = None
+        step1 = fused2 = window2 = fused3 = prev_headline = temporal3 = None
         verified, verification, host_slab, first_out = None, None, None, None     # the slab kernels' parity is tests/test_gpu_parity.py::test_c4_slab_views_at_full_size
         if not args.no_verify and not rehearse:      # (a rehearsal's self-neighbour exchange is not the physical one)
             verified, verification = verify_slab_run(torch, dist, run, sweep, (L, M, N) if w["ndim"] == 3 else (M, N), H, launches_per_step, iters, prank, pworld, dev, tdt)
@@ -957,6 +992,7 @@ def main(argv=None):
             out["config"]["exchange_calibration"] = calibration      # measured on this machine during warm-up (multigpu.measure_exchange_every)
         out["step1_kernel"] = step1                 # one time step per launch: highest roofline fraction
         out["temporal_step2_kernel"] = fused2       # on-chip temporal blocking (2 stages): equal to the headline up to rounding
+        out["temporal_step3_kernel"] = temporal3    # round 4: skewed 3-stage pipeline (fp64 workloads): equal to the fused --step 3 arithmetic within 1e-12
         # round 3: several time steps per launch with the reference's own fused --step n arithmetic, bit for bit (C3 / C4: --step 3, C2: --step 4)
         out["fused_multistep_kernel"] = fused3
         out["fused_step3_kernel"] = fused3 if (fused3 and fused3["step"] == 3) else None
@@ -971,8 +1007,14 @@ def main(argv=None):
             if oracle_check is not None:       # the CPU leg is also the checker of what was timed
                 out["verification"]["vs_cpu_oracle_slab"] = oracle_check
                 out["verified"] = bool(out["verified"] and oracle_check["ok"])
+            if temporal3 and temporal3.get("_slabs"):      # ... and of the 3-stage pipeline's launch (its own step: --step 3 arithmetic)
+                t3c = oracle_check_slabs(args.workload, temporal3["step"], temporal3.pop("_slabs"), True)
+                temporal3["verification"]["vs_cpu_oracle_slab"] = t3c
+                temporal3["verified"] = bool(temporal3["verified"] and t3c["ok"])
         else:
             out["cpu_baseline"] = None
+        if temporal3:
+            temporal3.pop("_slabs", None)
         sys.stdout.flush()
         os.write(result_fd, (json.dumps(out) + "\n").encode())
     if dist is not None:

@@ -178,7 +178,8 @@ MI355X options:
                         (default: 2 for 3D, 0 for 2D); 3 = like 2 with --zgroup <n> successive stream
                         blocks of a tile taken by consecutive workgroups; 4 = units of 32 consecutive tiles of one
                         stream block (the CUs of an XCD) dealt round-robin to the XCDs: neighbouring tiles run
-                        together on one XCD and share their halo reads in its L2.
+                        together on one XCD and share their halo reads in its L2; 5 = chunks of --xcd-chunk <n> (4)
+                        consecutive tiles per XCD and round (x neighbours share the lines of their x halos), one front.
 --nt-store <0|1>        Non-temporal stores of the output (1 by default).
 --nt-load <0|1>         Non-temporal loads of the input.
 --waves-per-eu <num>    Second argument of __launch_bounds__.
@@ -258,6 +259,7 @@ inline GenResult generate(const std::vector<std::string> &args /* argv[1..] */) 
         else if (a == "--clamp-loads") { if (!int_opt(o.clamp_loads, nullptr)) break; }
         else if (a == "--halo-spread") { if (!int_opt(o.halo_spread, nullptr)) break; }
         else if (a == "--zgroup") { if (!int_opt(o.zgroup, nullptr)) break; }
+        else if (a == "--xcd-chunk") { if (!int_opt(o.xcd_chunk, nullptr)) break; }
         else if (a == "--zigzag") { if (!int_opt(o.zigzag, nullptr)) break; }
         else if (a == "--pair-launch") { if (!int_opt(o.pair_launch, nullptr)) break; }
         else if (a == "--prefetch-auto") { if (!int_opt(o.prefetch_auto, nullptr)) break; }

@@ -89,6 +89,7 @@ struct GenOptions {
     int zigzag = 0;              // --zigzag 1: the launch whose output array lies below its input array (every second launch of a ping-pong)
                                  // takes its stream blocks in REVERSE order, so that it starts on the planes the previous launch wrote last
                                  // (still in the memory-side cache).  Which workgroup sweeps which block never changes a result
+    int xcd_chunk = 4;           // --xcd-remap 5: consecutive tiles an XCD takes per round
     int zgroup = 4;              // --xcd-remap 3: stream blocks of one tile taken by consecutive workgroups
     int prefetch_auto = 1;       // 3D kernels with step > 1 (fused or temporal) prefetch unless --prefetch-auto 0 (+28 % measured)
     int prefetch_depth = -1;     // planes in flight ahead of the one being summed (register sets = depth + 1); -1 auto:

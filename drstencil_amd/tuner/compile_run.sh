@@ -53,5 +53,5 @@ declare -A PMC=(
 for pass in ${DRS_PROFILE_PASSES:-fetch write tcc sq sq2 grbm}; do
   rm -rf prof/${name}/${pass}
   # a group this rocprofv3 / device cannot collect leaves no directory: getGpuMetrics.py writes empty cells for it
-  rocprofv3 --kernel-trace --pmc ${PMC[$pass]} --kernel-include-regex "${regex}" --output-format csv -d prof/${name}/${pass} -- bin/${name} > prof/${name}.${pass}.log 2>&1 || { echo "compile_run.sh: counter pass ${pass} failed for ${name}" >&2; rm -rf prof/${name}/${pass}; }
+  rocprofv3 --kernel-trace --pmc ${PMC[$pass]} --kernel-include-regex "${regex}" --output-format csv -d prof/${name}/${pass} -- bin/${name} > prof/${name}/${pass}.log 2>&1 || { echo "compile_run.sh: counter pass ${pass} failed for ${name}" >&2; rm -rf prof/${name}/${pass}; }
 done

@@ -620,11 +620,12 @@ def main():
                     help="after the search: the fastest verified configuration per (step, temporal, streaming) class becomes this stencil's row of "
                          "drstencil_amd/tuned_defaults.tsv (+ csrc/tuned_defaults.hpp; rebuild with make): the generator's defaults and bench.py's TUNED")
     ap.add_argument("--from-results", default=None, help="with --write-defaults: no search, take the records of this results.jsonl")
+    ap.add_argument("--defaults-table", default=None, help="with --write-defaults: write this table instead of drstencil_amd/tuned_defaults.tsv (no header regenerated: tests)")
     a = ap.parse_args()
     order, ndim, elem_bytes = a.order, (3 if a.is3d else 2), (4 if a.dtype == "fp32" else 8)
     if a.write_defaults and a.from_results:
         recs = [json.loads(l) for l in open(a.from_results) if l.strip()]
-        for row in write_defaults(os.path.abspath(a.stc), a.is3d, a.dtype, recs, a.from_results):
+        for row in write_defaults(os.path.abspath(a.stc), a.is3d, a.dtype, recs, a.from_results, table=a.defaults_table):
             print("tuned default:", row["mode"], row["shape"], "step", row["step"], row["dtype"], "N", row["N"], "|", row["options"])
         return
     if a.configs_file:
@@ -645,7 +646,7 @@ def main():
     res = searchSpace(os.path.abspath(a.stc), a.is3d, a.dtype, paras, a.out, budget_s=a.budget or None, jobs=a.jobs, profile_top=a.profile_top,
                       extra_opts=a.extra.split())
     if a.write_defaults:
-        for row in write_defaults(os.path.abspath(a.stc), a.is3d, a.dtype, res, os.path.join(a.out, "results.jsonl")):
+        for row in write_defaults(os.path.abspath(a.stc), a.is3d, a.dtype, res, os.path.join(a.out, "results.jsonl"), table=a.defaults_table):
             print("tuned default:", row["mode"], row["shape"], "step", row["step"], row["dtype"], "N", row["N"], "|", row["options"])
     print("best:")
     for r in res[:10]:

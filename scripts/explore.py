@@ -124,7 +124,7 @@ def main():
           if key not in bufs:
               # Buffers live for the whole run (288 GB of HBM): until this round's fix they were re-allocated whenever the grid changed, i.e.
               # once per round and grid, and the first ~140 ms of launches on a FRESH pair of 4 GiB arrays run the fused step-3 kernels
-              # 15-20 % slower (scripts/probe_cold.py) -- what earlier logs read as a configuration or a device being slow was the
+              # 15-20 % slower (scripts/archive/probe_cold.py) -- what earlier logs read as a configuration or a device being slow was the
               # position of the line in the file.  Both arrays sit in one arena at the first kernel's recommended skew, and every
               # pair is warmed for EXPLORE_WARM_S (default 0.4 s) before its first timing.
               tdt = torch.float32 if dtype == "fp32" else torch.float64

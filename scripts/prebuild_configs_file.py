@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """prebuild_configs_file.py <configs file> [<3D .stc>] -- compile every configuration of a tuner `--configs-file` (one raw option string per
-line, as scripts/tune_c4_s2_top.txt) for an fp32 3D spec into drstencil_amd/_kcache on THIS machine (no GPU needed), with the flags the
+line, as scripts/archive/tune_c4_s2_top.txt) for an fp32 3D spec into drstencil_amd/_kcache on THIS machine (no GPU needed), with the flags the
 round-3 sweeps use (`--3d --dtype fp32 --cc-opt -fno-slp-vectorize` in front), so that the tuner run on the GPU box only measures."""
 import os
 import sys

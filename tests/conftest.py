@@ -96,7 +96,8 @@ def _run_tuner_smoke():
     os.makedirs(out, exist_ok=True)
     try:
         r = subprocess.run([sys.executable, os.path.join(ROOT, "drstencil_amd", "tuner", "tuning.py"), os.path.join(ROOT, "tests", "stc", "t3_star.stc"),
-                            "--3d", "--dtype", "fp32", "--steps", "1,2", "--max-configs", "6", "--seed", "3", "--out", out, "--profile-top", "1"],
+                            "--3d", "--dtype", "fp32", "--steps", "1,2", "--max-configs", "6", "--seed", "3", "--out", out, "--profile-top", "1",
+                            "--write-defaults", "--defaults-table", os.path.join(out, "tuned_defaults.tsv")],      # the tuner -> generator loop, into a scratch table
                            capture_output=True, text=True, timeout=600)
         text = "[tuner rc=%d]\n%s%s" % (r.returncode, r.stdout[-4000:], r.stderr[-2000:])
     except Exception as e:

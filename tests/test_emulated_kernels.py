@@ -112,6 +112,8 @@ VARIANTS = [
     ("3d_xcd_units_s2", 3, "STAR3", (23, 37, 300), ["--3d", "--dtype", "fp32", "--sn", "7", "--step", "2", "--prefetch", "--xcd-remap", "4", "--bx", "32", "--by", "4", "--block-merge-y", "2"]),
     ("3d_xcd_units_many_tiles", 3, "STAR3", (12, 70, 530), ["--3d", "--dtype", "fp64", "--sn", "5", "--xcd-remap", "4", "--bx", "16", "--by", "2", "--block-merge-y", "2"]),
     ("2d_stream_xcd_units", 2, "BOX25", (1, 61, 1068), ["--dtype", "fp32", "--streaming", "--sn", "9", "--xcd-remap", "4", "--bx", "16"]),
+    ("2d_tile_xcd_chunks", 2, "BOX25", (1, 61, 1068), ["--dtype", "fp32", "--xcd-remap", "5", "--xcd-chunk", "3", "--bx", "16", "--by", "4", "--block-merge-y", "2"]),
+    ("3d_xcd_chunks_s2", 3, "STAR3", (23, 37, 300), ["--3d", "--dtype", "fp64", "--sn", "7", "--step", "2", "--xcd-remap", "5", "--bx", "16", "--by", "4", "--block-merge-y", "2"]),
     # round 4: --cyclic-merge-x is the reference's strided layout (codegen.hpp:116-141, `mi += blockDim.x`): a lane's points are Bx columns
     # apart, element-wide accesses, the x rim by DPP from the neighbouring lane's point of the same index
     ("3d_cyclicx_fp32", 3, "STAR3", (12, 17, 263), ["--3d", "--dtype", "fp32", "--sn", "5", "--cyclic-merge-x", "4", "--bx", "32", "--by", "4", "--block-merge-y", "2"]),

@@ -399,11 +399,26 @@ def test_tuner_search_end_to_end():
     assert float(rec["RMS Error"]) == 0.0 or (temporal_winner and float(rec["RMS Error"]) < 1e-6)      # the emitted program's own --check
     assert float(rec["FETCH_SIZE"]) >= 0 and float(rec["WRITE_SIZE"]) >= 0
     _check_why_columns(rec)
+    # round 4: the search closed the loop -- its fastest verified configuration per step became a row of the (scratch) defaults table,
+    # with the naming options stripped, and the lookup for this stencil finds it
+    from drstencil_amd import tuned_defaults as td
+    trows = td.load(os.path.join(out, "tuned_defaults.tsv"))
+    assert trows and "tuned default:" in text
+    stc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "stc", "t3_star.stc")
+    mode, shape, points, order, N = td.key_of(stc, 3)
+    for r in trows:
+        assert (r["mode"], r["shape"], r["dtype"], r["N"]) == (mode, shape, "fp32", N) and "--3d" not in r["options"] and "--step" not in r["options"] and "--bx" in r["options"]
+    bystep = {r["step"]: r for r in trows if not r["temporal"]}
+    for st_, r in bystep.items():
+        fastest = max((x for x in timed if x["step"] == st_ and x.get("verified") and x.get("arithmetic") != "reassociated"), key=lambda x: x["GStencil"], default=None)
+        assert fastest is not None and fastest["name"] in r["source"], (r, fastest)
 
 
 def _check_why_columns(rec):
     """Round 4: the "why" beside each profiled configuration (compile_run.sh's tcc / sq / sq2 / grbm passes -> getGpuMetrics.py)."""
-    assert 0.0 <= float(rec["L2 Hit Rate"]) <= 1.0 and 0.5 < float(rec["Effective Clock"]) < 3.5, rec
+    # (Effective Clock = GRBM busy cycles / 8 XCDs / the dispatch's own duration: on the few-microsecond launches of this toy grid the busy
+    # window is longer than the kernel's timestamps, so the figure overshoots the 2.4 GHz it shows on millisecond launches)
+    assert 0.0 <= float(rec["L2 Hit Rate"]) <= 1.0 and 0.3 < float(rec["Effective Clock"]) < 12.0, rec
     assert 0.0 <= float(rec["Waves Waiting"]) <= 1.0 and 0.0 <= float(rec["Issue Stalled"]) <= 1.0 and 0.0 <= float(rec["LDS Bank Conflicts"]) <= 1.0, rec
     assert float(rec["VALU Instructions"]) > 0 and float(rec["VMEM Read Instructions"]) > 0 and float(rec["VMEM Write Instructions"]) > 0 and float(rec["LDS Instructions"]) > 0, rec
     assert float(rec["Waves"]) > 0 and 1 <= int(rec["Occupancy"]) <= 8 and float(rec["Traffic / Algorithmic"]) >= 0, rec
@@ -512,6 +527,15 @@ def test_emitted_n_gpu_host():
     for one_rank in (b2, c2):                      # a one-rank world through the same code: the slab run == the gold kernel on the whole grid
         assert "rc=0" in one_rank and "[Test] RMS Error : 0.000000e+00" in one_rank and "on 1 GPU(s)," in one_rank
     assert "rc=0" in c and "[rank 1 of 3] planes [99, 201) of 301, owns [100, 200)" in c
+    # round 4: a rank that dies makes rank 0 end the others at once; a rank that hangs is ended by the watchdog; no spec
+    # files stay behind; the kernel names are stable, so a second run compiles nothing
+    import re
+    d_, e_, f_, g_ = part("d"), part("e"), part("f"), part("g")
+    assert "injected failure" in d_ and "a rank process failed" in (d_ + text) and re.search(r"rc=1 after [0-5] s", d_), d_
+    assert "watchdog" in (e_ + text) and re.search(r"rc=124 after ([2-9]|1[0-2]) s", e_), e_
+    assert f_.strip().endswith(": 0"), f_
+    m = re.search(r"rc=0 cache entries (\d+) -> (\d+)", g_)
+    assert m and m.group(1) == m.group(2), g_
 
 
 def test_c_host_through_the_abi():
