@@ -699,6 +699,7 @@ def main(argv=None):
         def reseed():
             A.copy_(R)
             B.zero_()
+        A0_, B0_ = A, B
         chunk = max(1, min(args.steps, int(0.9 * finite_steps) // max(1, launches_per_step * step)))
         ev_ms, el, n, done = 0.0, 0.0, 0, 0
         while done < args.steps:
@@ -718,11 +719,14 @@ def main(argv=None):
         kinfo = kern.info
         kres = kern.resources
         parallelism = "1 GPU"
-        def side(k, o, iters):
+        def side(k, o, iters, pair=None):
             # side measurement on the same grid (reference protocol: warm-up launches, then the timed
-            # ping-pong loop bracketed by HIP events)
+            # ping-pong loop bracketed by HIP events).  pair = (A, B) of the kernel's own arena (its own measured placement) instead of the headline's
             hz = k.info.get("tolerance_horizon_iterations", -1)
             reseed()                                          # finite data (see above); warm-up 4 launches + the loop stay inside the overflow horizon
+            A, B = (A0_, B0_) if pair is None else pair
+            if pair is not None:
+                A.copy_(R); B.zero_()
             iters = max(2 * k.info["step"], min(iters, int(0.8 * finite_steps) - 4 * k.info["step"]))
             if k.info.get("arithmetic") == "reassociated" and not k.info.get("temporal_forced") and 0 < hz < iters:
                 # a temporal pipeline keeps the tolerance up to its horizon only (drs_kernel_run refuses more): timed in loops of that length
@@ -743,7 +747,17 @@ def main(argv=None):
         prev_headline = side(kernp, PREV_HEADLINE[args.workload], 32) if kernp is not None else None
         temporal3 = None
         if kernt3 is not None:
-            temporal3 = side(kernt3, TEMPORAL3[args.workload], 24)
+            # its own arena: the pipeline's read front runs 7 planes ahead of its write front, so its good (out - in) mod 64 MiB differs from the
+            # headline's (profiles/r04_exp_r4c.log: 3.36 ms at 0 MiB, 3.26 at 32) -- measured on this device like the headline's
+            t3_pair = None
+            if args.placement != "separate":
+                At3, Bt3, _arena3 = kernt3.alloc_pair(torch, dev, dtype=tdt, calibrate=(args.placement == "measured"))
+                t3_pair = (At3, Bt3)
+            temporal3 = side(kernt3, TEMPORAL3[args.workload], 24, pair=t3_pair)
+            if t3_pair is not None:
+                temporal3["placement_out_minus_in_mod_period_bytes"] = kernt3.pair_skew_bytes
+                del At3, Bt3, _arena3, t3_pair
+                torch.cuda.empty_cache()
             temporal3["vgprs"], temporal3["lds_bytes"], temporal3["stages"] = kernt3.resources.get("vgprs"), kernt3.info["lds_bytes"], kernt3.info.get("stages")
             temporal3["drift_estimate"] = kernt3.info.get("drift_estimate")
             t3_traffic, t3_src = pmc_traffic(args.workload, " ".join(TEMPORAL3[args.workload]))
