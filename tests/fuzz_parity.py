@@ -58,6 +58,29 @@ def round3_knobs(rnd, cl):
     return cl
 
 
+def round4_knobs(rnd, cl):
+    """Round 4's knobs, drawn after round 3's: the skewed temporal pipeline (--skew 1 | 2: needs --prefetch, register staging), the XCD unit /
+    chunk maps, and --cyclic-merge-x as the strided layout (taps order, register staging, wherever the configuration merges points in x)."""
+    def setopt(name, value):
+        if name in cl:
+            cl[cl.index(name) + 1] = value
+        else:
+            cl.extend([name, value])
+    if "--temporal" in cl and "--stage" not in cl and rnd.random() < 0.6:
+        setopt("--skew", str(rnd.choice([1, 2])))
+        if "--prefetch" not in cl:
+            cl.append("--prefetch")
+    r = rnd.random()
+    if r < 0.2:
+        setopt("--xcd-remap", "4")
+    elif r < 0.35:
+        setopt("--xcd-remap", "5")
+        setopt("--xcd-chunk", str(rnd.choice([2, 3, 8])))
+    if rnd.random() < 0.2 and "--block-merge-x" in cl and "--order" not in cl and "--stage" not in cl:
+        cl[cl.index("--block-merge-x")] = "--cyclic-merge-x"
+    return cl
+
+
 def make_jobs(n, seed):
     """n random configurations (tuner space x test stencils x dtypes): (ndim, stc, dtype, drstencil args, step)."""
     random.seed(seed)
@@ -91,6 +114,10 @@ def make_jobs(n, seed):
                     cl += ["--defer-stores", "1"]
                 if ROUND3:
                     round3_knobs(random, cl)
+                    if os.environ.get("FUZZ_ROUND4", "1") != "0":
+                        round4_knobs(random, cl)
+                        if "--skew" in cl and ndim == 2 and "--streaming" not in cl:
+                            del cl[cl.index("--skew"):cl.index("--skew") + 2]          # one-shot 2D tiles have no stream to skew
                 args = (["--3d"] if ndim == 3 else []) + ["--dtype", dtype] + cl + [stc]
                 jobs.append((ndim, stc, dtype, args, v[0]))
     return jobs

@@ -113,6 +113,9 @@ def make_jobs(nshapes, per, seed):
                     cl += ["--defer-stores", "1"]
                 if fp.ROUND3:
                     fp.round3_knobs(rnd, cl)
+                    fp.round4_knobs(rnd, cl)
+                    if "--skew" in cl and ndim == 2 and "--streaming" not in cl:
+                        del cl[cl.index("--skew"):cl.index("--skew") + 2]
                 args = (["--3d"] if ndim == 3 else []) + ["--dtype", dtype] + cl + [stc]
                 if not t.registerFilter(args):   # the tuner's spill model: do not compile what would be refused for scratch
                     dropped[0] += 1

@@ -360,6 +360,9 @@ def _emulated_fuzz_jobs(n=14, seed=9):
                     cl += ["--defer-stores", "1"]          # LDS-DMA staging (16-byte vectors: the generator rejects the others)
                 import fuzz_parity
                 fuzz_parity.round3_knobs(rnd, cl)          # round 3: rows order / packed pairs / pinned sums / rotation modulus / loader wavefronts
+                fuzz_parity.round4_knobs(rnd, cl)          # round 4: skewed pipelines, XCD unit / chunk maps, strided x merge
+                if "--skew" in cl and ndim == 2 and "--streaming" not in cl:
+                    del cl[cl.index("--skew"):cl.index("--skew") + 2]
                 jobs.append((t.cfgToString(v) + "_" + dtype + "_%dd" % ndim + pts.lower(), ndim, pts, dims, (["--3d"] if ndim == 3 else []) + ["--dtype", dtype] + cl, v[0]))
     return jobs
 
