@@ -883,11 +883,12 @@ def main(argv=None):
             #     moment to trust a model fitted on one-GPU rehearsals.  The trial decides; the model's choice is reported beside it.
             model_every, calibration = measure_exchange_every(torch, dist, dims_, H, prank, pworld, sweep, dev, tdt, self_neighbour=bool(rehearse))
             runs, trial = {}, {}
+            from drstencil_amd.multigpu import slab_bounds
+            thinnest = min(slab_bounds(dims_[0], pworld, r_)[1] - slab_bounds(dims_[0], pworld, r_)[0] for r_ in range(pworld))
             for ev in (1, 2):
-                try:
-                    runs[ev] = make_run(ev)
-                except ValueError:           # slabs too thin for ghosts twice as wide (every rank raises alike: SlabPlan only knows the sizes)
+                if thinnest < 2 * ev * H:    # some rank's slab is too thin for ghosts this wide: decided from ALL ranks' sizes, so every rank skips alike
                     continue
+                runs[ev] = make_run(ev)
                 fill_finite(runs[ev], 1 + prank)
                 for _ in range(2):
                     runs[ev].run()

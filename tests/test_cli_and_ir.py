@@ -145,7 +145,8 @@ def test_temporal_fallback_is_reported(tmp_path):
     assert "note: --temporal 1 ignored" in msg and "// note: --temporal 1 ignored" in src
     assert '\\"stages\\":1' in src
     rc, msg, src = drs.generate(["--3d", "--dtype", "fp32", "--step", "2", "--temporal", "1", os.path.join(ROOT, "tests", "stc", "t3_star.stc")])
-    assert rc == 0 and "note:" not in msg and '\\"stages\\":2' in src
+    # (a note about the tuned-defaults table may appear for this stencil and size; none about --temporal)
+    assert rc == 0 and "--temporal 1 ignored" not in msg and "not honoured" not in msg and '\\"stages\\":2' in src
 
 
 def test_temporal_blocking_is_fenced_to_the_tolerance(tmp_path):
@@ -262,7 +263,8 @@ def test_tuner_writes_the_defaults_table(tmp_path):
     rows = t.write_defaults(stc4, True, "fp32", recs, "unit test", table=table)
     assert sorted((r["temporal"], r["options"]) for r in rows) == [(0, "--bx 64 --by 8 --sn 8 --pin 1"), (1, "--bx 66 --by 15")]
     after = td.load(table)
-    assert len(after) == len(before) + 1          # the fused row replaced c4's, the temporal row is new
+    key = lambda r: tuple(r[f] for f in td.FIELDS)
+    assert {key(r) for r in after} == {key(r) for r in before} | {key(r) for r in rows}          # rows of the same class and size are replaced, the others stay
     mode, shape, points, order, N = td.key_of(stc4, 3)
     assert td.lookup(mode, shape, 2, "fp32", 0, N, after) == "--bx 64 --by 8 --sn 8 --pin 1".split()
     assert td.lookup(mode, shape, 2, "fp32", 1, N, after) == ["--bx", "66", "--by", "15"]
