@@ -158,7 +158,8 @@ struct GenOptions {
                                  // in the info JSON / the banner and honoured by the emitted host program, which owns its allocations
     int tuned_defaults = 1;      // --tuned-defaults 0: never consult the tuner's table (generator.hpp)
     bool tuning_given = false;   // some option other than the problem-naming ones was given
-    int skew = 0;                // --skew 1 (round 4; temporal pipelines of streaming kernels, with --prefetch): stage t consumes the plane stage t-1 completed
+    int skew = -1;               // -1 auto: 1 for pipelines of three or more stages (measured: fp64 3 stages 3.49 -> 3.28 ms; 2 stages lose), else 0.
+                                 // --skew 1 (round 4; temporal pipelines of streaming kernels, with --prefetch): stage t consumes the plane stage t-1 completed
                                  // in the PREVIOUS iteration.  All stages of one iteration are then independent of each other: they run back to back
                                  // between two barriers -- [barrier] every stage reads its arriving plane's rim from its own LDS slot, the last stage first
                                  // (its stores leave early) [barrier] every stage's completed plane and the next source plane are written to the slots --

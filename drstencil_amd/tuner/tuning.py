@@ -94,6 +94,8 @@ def FilterParams(spaceVector):
     ldsUsage = slots * (ty + 2 * stage_halo) * (tx + 8) * elem_bytes
     if temporal and step == 1:
         return False
+    if temporal == "skew" and (not prefetch or not (ndim == 3 or streaming)):
+        return False              # the skewed pipeline stages its source plane from prefetch registers and needs a stream
     # (register demand is not estimated here: registerFilter() asks the generator, which knows the stencil's shape)
     if schedule not in ("scatter", "reuse"):
         return False
@@ -155,7 +157,9 @@ _PIECES = [
     ("--merge-forward {0}",                            "mf{0}",              lambda c: (c.merge_forward,),           lambda c: True),
     ("--prefetch --prefetch-depth {0}",                "p{1}",               lambda c: (c.depth, "" if c.depth == 1 else c.depth), lambda c: c.depth > 0),
     ("--xrim {0} --xcd-remap {1}",                     "x{2}m{1}",           lambda c: (c.xrim, c.xcd, c.xrim[0]),   lambda c: True),
-    ("--temporal 1",                                   "t",                  lambda c: (),                           lambda c: c.temporal),
+    ("--temporal 1",                                   "t",                  lambda c: (),                           lambda c: c.temporal is True),
+    # round 4: the skewed pipeline (stage t consumes what stage t-1 completed one iteration earlier; exact source-plane halo)
+    ("--temporal 1 --skew 1 --exact-y 1",              "ts",                 lambda c: (),                           lambda c: c.temporal == "skew"),
     ("--streaming",                                    "s",                  lambda c: (),                           lambda c: c.streaming),
     # --dist is always on the command line (reference scheme) and alone selects the reuse schedule: scatter is spelled out
     ("--schedule scatter",                             "",                   lambda c: (),                           lambda c: c.schedule == "scatter"),
@@ -178,7 +182,7 @@ def cfgToString(spaceVector):
     return "".join(_PIECES[i][1].format(*_PIECES[i][2](c)) for i in _NAME_ORDER if _PIECES[i][3](c))
 
 
-def enumerate_space(steps=(1,), full=False, emits=("taps",)):
+def enumerate_space(steps=(1,), full=False, emits=("taps",), round4=False):
     """The sweep space.  Lane counts include non-powers of two: with temporal blocking a tile owns
     mx*bx - 2*roundup((step-1)*order, mx) columns, so e.g. bx = 66 (264 columns, 256 owned) tiles a
     1024-wide grid exactly where bx = 64 would need a fifth tile."""
@@ -193,6 +197,8 @@ def enumerate_space(steps=(1,), full=False, emits=("taps",)):
         bys = [1, 2, 4, 8, 15, 16]
         sns = [8, 16, 32, 64, 128]
         mys = [1, 2, 4, 8, 16]
+    if round4 and ndim == 3:
+        sns = sns + [128, 256]     # long stream blocks: the z halo of an n-stage pipeline is n * order planes per block
     blockSizes = [(bx, by) for bx in bxs for by in bys if bx * by <= 2 ** maxThreadsPerBlockLg2]
     space = itertools.product(
         list(steps),
@@ -204,8 +210,8 @@ def enumerate_space(steps=(1,), full=False, emits=("taps",)):
         [5],
         [0, 1, 3] if ndim == 3 else [0, 1],   # software prefetch: planes in flight (0 = off)
         ["dpp"] if not full else ["lds", "dpp"],
-        [False, True],             # temporal blocking (only meaningful for step > 1)
-        [0, 2] if ndim == 3 else [0],
+        [False, True, "skew"] if round4 else [False, True],             # temporal blocking (only meaningful for step > 1); round 4: the skewed pipeline
+        ([0, 2, 4] if round4 else [0, 2]) if ndim == 3 else [0],                  # workgroup -> tile map (round 4: XCD work units)
         [False] if ndim == 3 else [False, True],   # 2D: one-shot tile kernel or --streaming (rows streamed)
     )
     out = []
@@ -611,6 +617,8 @@ def main():
     ap.add_argument("--configs-file", default=None, help="file with one raw option string per line instead of the space")
     ap.add_argument("--profile-top", type=int, default=0, help="after the search: rocprofv3 counters of the best N configurations -> <out>/gpuMetrics.csv (reference flow)")
     ap.add_argument("--jobs", type=int, default=16, help="compile workers")
+    ap.add_argument("--space", default="r3", choices=["r3", "r4"], help="r4: + the skewed temporal pipeline, the XCD unit map (--xcd-remap 4), 128- / 256-plane stream blocks")
+    ap.add_argument("--only", default="", help="comma-separated filters on the space: temporal | fused | skew")
     ap.add_argument("--emit", default="taps", help="comma-separated emissions to sweep: taps (rounds 1-2), pin, rows, rowspk (round 3)")
     ap.add_argument("--extra", default="", help="generator options added to every configuration (e.g. \"--cc-opt -fno-slp-vectorize\")")
     ap.add_argument("--placement", default=None, choices=["measured", "kernel"],
@@ -631,7 +639,9 @@ def main():
     if a.configs_file:
         paras = [l.strip() for l in open(a.configs_file) if l.strip() and not l.startswith("#")]
     else:
-        paras = enumerate_space(tuple(int(s) for s in a.steps.split(",")), emits=tuple(a.emit.split(",")))
+        paras = enumerate_space(tuple(int(s) for s in a.steps.split(",")), emits=tuple(a.emit.split(",")), round4=(a.space == "r4"))
+        for f in [x for x in a.only.split(",") if x]:
+            paras = [v for v in paras if {"temporal": bool(v[12]), "fused": not v[12], "skew": v[12] == "skew"}[f]]
         random.seed(a.seed)
         random.shuffle(paras)
         if a.max_configs:
