@@ -111,7 +111,13 @@ TUNED = _tuned()
 # the same workloads with one time step per launch: highest roofline fraction.  Full-row tiles (256 lanes x 4
 # points = N), 2 lane rows x 4 rows, 4-plane stream blocks, prefetch: the optimum of the exhaustive 1520-configuration
 # search (profiles/r01_tune_c4_s1_exhaustive.txt) -- 80 % of the HBM peak, the chip's measured copy ceiling
-STEP1 = {w: __import__("drstencil_amd.tuned_defaults", fromlist=["x"]).options_for(WORKLOADS[w]["stc"], 3, "fp32") for w in ("c4", "c3")}     # the table's step-1 rows
+def _step1(workloads):
+    from drstencil_amd import tuned_defaults as td
+    rows = td.load()
+    return {w: td.options_for(WORKLOADS[w]["stc"], WORKLOADS[w]["ndim"], WORKLOADS[w]["dtype"], rows=rows) for w in workloads}
+
+
+STEP1 = _step1(("c4", "c3"))      # the table's step-1 rows
 # on-chip temporal blocking (two applications of the one-step stencil per launch; equal to the fused stencil up to
 # rounding, 6.8e-7 relative at full size): 66 lanes x 4 = 264 columns own 256, so 4 tiles cover N = 1024 exactly
 def _temporal(step, workloads):

@@ -23,11 +23,14 @@ HEADER = ["Metric Name", "Duration", "Calls", "FETCH_SIZE", "WRITE_SIZE", "HBM T
           # round 4: why it is as fast as it is
           "Traffic / Algorithmic", "L2 Hit Rate", "Effective Clock", "Waves Waiting", "Issue Stalled", "Issue Busy", "LDS Bank Conflicts", "VALU Busy",
           "VALU Instructions", "VMEM Read Instructions", "VMEM Write Instructions", "LDS Instructions", "SALU Instructions", "Branch Instructions",
-          "Waves", "Occupancy"]
+          "Waves", "Occupancy",
+          # ... and figures derived from the above, named after the reference's columns where one exists
+          "Memory Throughput", "Read Throughput", "Write Throughput", "Elapsed Cycles", "Executed Instructions", "Executed Ipc Elapsed", "Waves Per CU", "Threads"]
 UNITS = ["", "nsecond", "", "KiB", "KiB", "byte", "byte", "GB/s", "of 8 TB/s", "", "", "", "byte", "", "", "ms", "", "", "byte/lane", "",
          "", "of L2 requests", "GHz", "of wave cycles", "of wave cycles", "of wave cycles", "of LDS cycles", "of wave cycles",
          "wave instructions", "wave instructions", "wave instructions", "wave instructions", "wave instructions", "wave instructions",
-         "", "waves/SIMD"]
+         "", "waves/SIMD",
+         "GB/s (HBM, counters)", "GB/s", "GB/s", "cycle (busy, per XCD)", "wave instructions", "wave instructions / cycle / CU", "", ""]
 
 
 def _one(pattern):
@@ -91,6 +94,15 @@ def main(name=""):
            ratio("SQ_LDS_BANK_CONFLICT", "SQ_LDS_IDX_ACTIVE"), (vals["SQ_ACTIVE_INST_VALU"] / vals["SQ_WAVE_CYCLES"]) if "SQ_ACTIVE_INST_VALU" in vals and vals.get("SQ_WAVE_CYCLES") else "",
            vals.get("SQ_INSTS_VALU", ""), vals.get("SQ_INSTS_VMEM_RD", ""), vals.get("SQ_INSTS_VMEM_WR", ""), vals.get("SQ_INSTS_LDS", ""), vals.get("SQ_INSTS_SALU", ""),
            vals.get("SQ_INSTS_BRANCH", ""), vals.get("SQ_WAVES", ""), occ.group(1) if occ else ""]
+    insts = [vals[k] for k in ("SQ_INSTS_VALU", "SQ_INSTS_VMEM_RD", "SQ_INSTS_VMEM_WR", "SQ_INSTS_LDS", "SQ_INSTS_SALU", "SQ_INSTS_BRANCH") if k in vals]
+    cycles = vals["GRBM_GUI_ACTIVE"] / 8.0 if "GRBM_GUI_ACTIVE" in vals else None
+    try:
+        threads = int(meta.get("Grid_Size", ""))
+    except ValueError:
+        threads = ""
+    why += [traffic / dur if traffic == traffic and dur == dur and dur > 0 else "", fetch * 2048 / dur if fetch == fetch and dur == dur and dur > 0 else "",
+            write * 1024 / dur if write == write and dur == dur and dur > 0 else "", cycles if cycles else "", sum(insts) if insts else "",
+            sum(insts) / cycles / 256.0 if insts and cycles else "", vals["SQ_WAVES"] / 256.0 if "SQ_WAVES" in vals else "", threads]
     row = [name, dur, calls, fetch, write, traffic, alg, gbs, gbs / 8000.0, interior * mac.get("Step", 1) / dur if dur == dur and dur > 0 else float("nan"),
            meta.get("Grid_Size", ""), meta.get("Workgroup_Size", ""), meta.get("LDS_Block_Size", ""), meta.get("VGPR_Count", ""), meta.get("SGPR_Count", ""),
            t.group(1) if t else "", rms.group(1) if rms else "", _rep("AGPRs:"), _rep("ScratchSize [bytes/lane]:"), _rep("VGPRs Spill:")] + why
