@@ -63,6 +63,12 @@ def main():
                     cl += ["--stage", "dma"]
                 if random.random() < 0.3:
                     cl += ["--defer-stores", "1"]
+                if os.environ.get("FUZZ_ROUND4", "1") != "0":     # rounds 3 and 4's knobs on top (drawn last): rows order / pinned sums / ...; skewed pipelines, XCD maps, strided x merge
+                    import fuzz_parity as fp
+                    fp.round3_knobs(random, cl)
+                    fp.round4_knobs(random, cl)
+                    if "--skew" in cl and ndim == 2 and "--streaming" not in cl:
+                        del cl[cl.index("--skew"):cl.index("--skew") + 2]
                 jobs.append((ndim, dtype, (["--3d"] if ndim == 3 else []) + ["--dtype", dtype] + cl + [stc], dims))
     t0 = time.time()
     with ProcessPoolExecutor(max_workers=int(os.environ.get("FUZZ_JOBS", "16"))) as ex:
