@@ -19,7 +19,10 @@ import fuzz_shapes as fs
 
 CACHE = os.environ.get("DRS_KCACHE", os.path.join(ROOT, "drstencil_amd", "_kcache"))
 OPTION_SETS_3D = [["--sn", "8"], ["--sn", "16", "--prefetch"], ["--sn", "8", "--schedule", "window"], ["--sn", "12", "--dist", "{d}"], ["--sn", "8", "--step", "2"],
-                  ["--sn", "8", "--step", "2", "--dist", "{d2}", "--prefetch"], ["--sn", "8", "--stage", "dma"], ["--sn", "16", "--step", "2", "--schedule", "scatter", "--prefetch", "--prefetch-depth", "2"]]
+                  ["--sn", "8", "--step", "2", "--dist", "{d2}", "--prefetch"], ["--sn", "8", "--stage", "dma"], ["--sn", "16", "--step", "2", "--schedule", "scatter", "--prefetch", "--prefetch-depth", "2"],
+                  # round 4: the XCD unit / chunk maps and the strided x merge in slab-view kernels
+                  ["--sn", "8", "--step", "2", "--xcd-remap", "4"], ["--sn", "8", "--xcd-remap", "5", "--xcd-chunk", "3", "--prefetch"],
+                  ["--sn", "8", "--cyclic-merge-x", "2", "--bx", "32", "--by", "4", "--block-merge-y", "2"]]
 OPTION_SETS_2D = [[], ["--streaming", "--sn", "16"], ["--streaming", "--sn", "32", "--prefetch", "--dist", "{d}"], ["--step", "2"], ["--streaming", "--sn", "16", "--step", "2", "--schedule", "scatter"]]
 
 
