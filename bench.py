@@ -133,6 +133,10 @@ TEMPORAL2 = _temporal(2, ("c4", "c3"))
 # 3.21 ms per launch at 1024^3 = 986 GStencil/s against 868 for the fused --step 3 kernel and 730 for the step-2 headline
 # (profiles/r04_exp_r4b/d.log); 1.6e-15 from the fused arithmetic (bar 1e-12, tolerance horizon 112 386 iterations)
 TEMPORAL3 = _temporal(3, ("c4f64", "c3f64"))
+# ... and FOUR stages: 726-lane workgroups (66 x 11 lanes, 12 wavefronts = 3 per SIMD: 151-163 VGPRs hold the 12 planes of sums), 132 x 22 tiles
+# that own 128 x 16, two planes of prefetch: 4.08-4.17 ms per launch of four time steps = 1005-1028 GStencil/s at 1024^3 (profiles/r04_exp_r4p/q.log)
+TEMPORAL4 = _temporal(4, ("c4f64", "c3f64"))
+TEMPORALS = {w: [(3, TEMPORAL3[w]), (4, TEMPORAL4[w])] for w in TEMPORAL3}
 # round 2: the same fused stencil with rotating register windows instead of carried partial sums (--schedule window): 126 VGPRs with
 # -fno-slp-vectorize and --waves-per-eu 4, no scratch, so TWO 512-lane workgroups share a CU (one reads while the other writes) and 8-plane
 # stream blocks cost nothing: +0.8 % over the headline in interleaved runs on one box (profiles/r02_exp_r2j/k_*.log) -- a side measurement
@@ -216,6 +220,7 @@ def kernels():
     out += [("bench_%s_step1" % w, w, STEP1[w]) for w in sorted(STEP1)]
     out += [("bench_%s_temporal2" % w, w, TEMPORAL2[w]) for w in sorted(TEMPORAL2)]
     out += [("bench_%s_temporal3" % w, w, TEMPORAL3[w]) for w in sorted(TEMPORAL3)]
+    out += [("bench_%s_temporal4" % w, w, TEMPORAL4[w]) for w in sorted(TEMPORAL4)]
     out += [("bench_%s_window_two_workgroups" % w, w, WINDOW2WG[w]) for w in sorted(WINDOW2WG)]
     out += [("bench_%s_fused3_%d" % (w, i), w, o) for w in sorted(FUSED3) for i, o in enumerate(FUSED3[w])]
     return out
@@ -577,15 +582,16 @@ def main(argv=None):
             L *= pworld
         else:
             M *= pworld
-    kern1 = kernf = kernw = kernp = kernt3 = None
+    kern1 = kernf = kernw = kernp = None
+    kernts = []
     kern3 = []
     if pworld == 1:
         kern = drs.Kernel(opts + [w["stc"]])
         if args.workload in STEP1 and not args.kernel_args and not args.headline_only:
             kern1 = drs.Kernel(STEP1[args.workload] + [w["stc"]])
             kernf = drs.Kernel(TEMPORAL2[args.workload] + [w["stc"]])
-        if args.workload in TEMPORAL3 and not args.kernel_args and not args.headline_only:
-            kernt3 = drs.Kernel(TEMPORAL3[args.workload] + [w["stc"]])
+        if args.workload in TEMPORALS and not args.kernel_args and not args.headline_only:
+            kernts = [(st_, drs.Kernel(o_ + [w["stc"]]), o_) for st_, o_ in TEMPORALS[args.workload]]
         if not args.kernel_args and not args.headline_only:
             for o3 in FUSED3.get(args.workload, []):
                 try:
@@ -751,29 +757,27 @@ def main(argv=None):
         fused2 = side(kernf, TEMPORAL2[args.workload], 32) if kernf is not None else None
         window2 = side(kernw, WINDOW2WG[args.workload], 32) if kernw is not None else None
         prev_headline = side(kernp, PREV_HEADLINE[args.workload], 32) if kernp is not None else None
-        temporal3 = None
-        if kernt3 is not None:
-            # its own arena: the pipeline's read front runs 7 planes ahead of its write front, so its good (out - in) mod 64 MiB differs from the
-            # headline's (profiles/r04_exp_r4c.log: 3.36 ms at 0 MiB, 3.26 at 32) -- measured on this device like the headline's
-            t3_pair = None
+        temporals = {}
+        for st_, kt, ot in kernts:
+            # its own arena: the pipeline's read front runs several planes further ahead of its write front than the headline's, so its good
+            # (out - in) mod 64 MiB differs (profiles/r04_exp_r4c.log: 3.36 ms at 0 MiB, 3.26 at 32) -- measured on this device like the headline's
+            t_pair = None
             if args.placement != "separate":
-                At3, Bt3, _arena3 = kernt3.alloc_pair(torch, dev, dtype=tdt, calibrate=(args.placement == "measured"))
-                t3_pair = (At3, Bt3)
-            temporal3 = side(kernt3, TEMPORAL3[args.workload], 24, pair=t3_pair)
-            if t3_pair is not None:
-                temporal3["placement_out_minus_in_mod_period_bytes"] = kernt3.pair_skew_bytes
-                del At3, Bt3, _arena3, t3_pair
+                At_, Bt_, _arena_t = kt.alloc_pair(torch, dev, dtype=tdt, calibrate=(args.placement == "measured"))
+                t_pair = (At_, Bt_)
+            tk = side(kt, ot, 8 * st_, pair=t_pair)
+            if t_pair is not None:
+                tk["placement_out_minus_in_mod_period_bytes"] = kt.pair_skew_bytes
+                del At_, Bt_, _arena_t, t_pair
                 torch.cuda.empty_cache()
-            temporal3["vgprs"], temporal3["lds_bytes"], temporal3["stages"] = kernt3.resources.get("vgprs"), kernt3.info["lds_bytes"], kernt3.info.get("stages")
-            temporal3["drift_estimate"] = kernt3.info.get("drift_estimate")
-            t3_traffic, t3_src = pmc_traffic(args.workload, " ".join(TEMPORAL3[args.workload]))
-            temporal3["traffic"], temporal3["traffic_source"] = t3_traffic, t3_src
+            tk["vgprs"], tk["lds_bytes"], tk["stages"], tk["threads"] = kt.resources.get("vgprs"), kt.info["lds_bytes"], kt.info.get("stages"), kt.info["threads"]
+            tk["drift_estimate"] = kt.info.get("drift_estimate")
+            tk["traffic"], tk["traffic_source"] = pmc_traffic(args.workload, " ".join(ot))
             if not args.no_verify:      # like the headline: one launch against the gold kernel on the whole grid (tolerance) + three oracle slabs (CPU leg)
                 g3 = torch.Generator(device=dev).manual_seed(1)
                 A.copy_(torch.rand(shape, dtype=tdt, device=dev, generator=g3))
-                t3_ok, t3_ver, _, t3_slabs = verify_timed_kernel(torch, kernt3, args.workload, A, B, True)
-                temporal3["verified"], temporal3["verification"] = t3_ok, t3_ver
-                temporal3["_slabs"] = t3_slabs
+                tk["verified"], tk["verification"], _, tk["_slabs"] = verify_timed_kernel(torch, kt, args.workload, A, B, True)
+            temporals[st_] = tk
         fused3 = None
         if kern3:
             # every candidate timed on THIS device, on finite data (side() restores the pristine input first), the fastest reported in full
@@ -957,7 +961,8 @@ def main(argv=None):
         if args.slab_runtime == "native":
             calibration = dict(calibration or {}, native_runtime=run.slab.info)
         parallelism = "%s-slab x%d%s, RCCL send/recv halo every %d launch(es), overlapped" % ("z" if w["ndim"] == 3 else "y", pworld, " (weak: grid %s)" % "x".join(str(d) for d in ((L, M, N) if w["ndim"] == 3 else (M, N))) if weak else "", args.exchange_every)
-        step1 = fused2 = window2 = fused3 = prev_headline = temporal3 = None
+        step1 = fused2 = window2 = fused3 = prev_headline = None
+        temporals = {}
         verified, verification, host_slab, first_out = None, None, None, None     # the slab kernels' parity is tests/test_gpu_parity.py::test_c4_slab_views_at_full_size
         if not args.no_verify and not rehearse:      # (a rehearsal's self-neighbour exchange is not the physical one)
             verified, verification = verify_slab_run(torch, dist, run, sweep, (L, M, N) if w["ndim"] == 3 else (M, N), H, launches_per_step, iters, prank, pworld, dev, tdt)
@@ -1013,7 +1018,9 @@ def main(argv=None):
             out["config"]["exchange_calibration"] = calibration      # measured on this machine during warm-up (multigpu.measure_exchange_every)
         out["step1_kernel"] = step1                 # one time step per launch: highest roofline fraction
         out["temporal_step2_kernel"] = fused2       # on-chip temporal blocking (2 stages): equal to the headline up to rounding
-        out["temporal_step3_kernel"] = temporal3    # round 4: skewed 3-stage pipeline (fp64 workloads): equal to the fused --step 3 arithmetic within 1e-12
+        # round 4: skewed 3- and 4-stage pipelines (fp64 workloads): equal to the fused --step 3 / 4 arithmetic within 1e-12
+        out["temporal_step3_kernel"] = temporals.get(3)
+        out["temporal_step4_kernel"] = temporals.get(4)
         # round 3: several time steps per launch with the reference's own fused --step n arithmetic, bit for bit (C3 / C4: --step 3, C2: --step 4)
         out["fused_multistep_kernel"] = fused3
         out["fused_step3_kernel"] = fused3 if (fused3 and fused3["step"] == 3) else None
@@ -1028,14 +1035,15 @@ def main(argv=None):
             if oracle_check is not None:       # the CPU leg is also the checker of what was timed
                 out["verification"]["vs_cpu_oracle_slab"] = oracle_check
                 out["verified"] = bool(out["verified"] and oracle_check["ok"])
-            if temporal3 and temporal3.get("_slabs"):      # ... and of the 3-stage pipeline's launch (its own step: --step 3 arithmetic)
-                t3c = oracle_check_slabs(args.workload, temporal3["step"], temporal3.pop("_slabs"), True)
-                temporal3["verification"]["vs_cpu_oracle_slab"] = t3c
-                temporal3["verified"] = bool(temporal3["verified"] and t3c["ok"])
+            for tk in temporals.values():      # ... and of the pipelines' launches (their own step: the fused --step n arithmetic)
+                if tk.get("_slabs"):
+                    tc = oracle_check_slabs(args.workload, tk["step"], tk.pop("_slabs"), True)
+                    tk["verification"]["vs_cpu_oracle_slab"] = tc
+                    tk["verified"] = bool(tk["verified"] and tc["ok"])
         else:
             out["cpu_baseline"] = None
-        if temporal3:
-            temporal3.pop("_slabs", None)
+        for tk in temporals.values():
+            tk.pop("_slabs", None)
         sys.stdout.flush()
         os.write(result_fd, (json.dumps(out) + "\n").encode())
     if dist is not None:

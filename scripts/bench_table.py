@@ -19,7 +19,7 @@ for w in order:
     opts = d["config"]["generator_options"]
     opts = re.sub(r"^(--3d )?--dtype fp(32|64) ?", "", opts)
     side = []
-    for key, label in (("step1_kernel", "step 1"), ("fused_multistep_kernel", "fused step %s"), ("temporal_step2_kernel", "temporal 2 stages"), ("temporal_step3_kernel", "**temporal 3 stages**")):
+    for key, label in (("step1_kernel", "step 1"), ("fused_multistep_kernel", "fused step %s"), ("temporal_step2_kernel", "temporal 2 stages"), ("temporal_step3_kernel", "**temporal 3 stages**"), ("temporal_step4_kernel", "**temporal 4 stages**")):
         s = d.get(key)
         if s:
             lab = label % s["step"] if "%s" in label else label
