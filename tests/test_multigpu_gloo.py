@@ -229,7 +229,7 @@ def test_exchange_decision_rule():
 
 
 def _calib_worker(rank, world, port, us_per_plane, q):
-    """measure_exchange_every on CPU ranks over gloo: a `sweep` that takes 400 us per plane and a link that takes `us_per_plane` per plane
+    """measure_exchange_every on CPU ranks over gloo: a `sweep` that takes 10 ms + 400 us per plane and a link that takes `us_per_plane` per plane
     sent (the sleep is inside the exchange of THIS run's process group, i.e. where a slow xGMI link would show)."""
     import time
     sys.path.insert(0, ROOT)
@@ -246,7 +246,7 @@ def _calib_worker(rank, world, port, us_per_plane, q):
     mg.batch_p2p = slow_link
 
     def sweep(src, dst, stream):
-        time.sleep(src.shape[0] * 400e-6)
+        time.sleep(10e-3 + src.shape[0] * 400e-6)          # a launch costs a fixed 10 ms + 0.4 ms per plane: separate boundary launches are what every = 2 saves
     every, m = mg.measure_exchange_every(torch, dist, (256, 8, 16), 2, rank, world, sweep, torch.device("cpu"), torch.float32, reps=3)
     q.put((rank, every, m))
     dist.barrier()
@@ -255,10 +255,10 @@ def _calib_worker(rank, world, port, us_per_plane, q):
 
 @pytest.mark.parametrize("us_per_plane,expected", [(50.0, 2), (30000.0, 1)])
 def test_slow_link_flips_the_exchange_mode(us_per_plane, expected):
-    """world 2 over gloo, 128 planes per rank, H = 2: an interior sweep takes ~50 ms (sleeps long enough to stand out of a loaded test
-    machine's noise).  A link at 50 us per plane hides 4 planes under it (one exchange per pair); at 30 ms per plane the 4-plane exchange
-    takes 120 ms and the 2-plane one 60 ms -- the calibration must flip to an exchange per launch, on every rank alike, and say that the
-    ranks agreed."""
+    """world 2 over gloo, 128 planes per rank, H = 2: an interior sweep takes ~60 ms, a boundary launch ~12 ms (sleeps long enough to stand
+    out of a loaded test machine's noise).  With a link at 50 us per plane one exchange per pair wins (it saves a boundary launch per pair:
+    ~135 against ~144 ms); at 30 ms per plane the 4-plane exchange takes 120 ms and no longer hides under one sweep, the 2-plane one (60 ms)
+    still does -- the calibration must flip to an exchange per launch, on every rank alike, and say that the ranks agreed."""
     world = 2
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
