@@ -303,7 +303,10 @@ def registerFilter(args):
         # round 3: with --pin / --order rows the compiler can no longer sink the FMA chains and stretch the source windows over
         # `Range` iterations, so what it allocates is the generator's named state plus addressing (measured: 98-136 VGPRs for
         # reg_demand 100-136, profiles/r03_exp_r3a.log); the logistic model above was fitted to unpinned kernels
-        return info["reg_demand"] + 24 <= min(256, lane_register_budget(info["threads"]))
+        # (pinned PIPELINES, round 4: the generator's figure for them is within ~7 registers of what the compiler allocates -- 120 named / 126
+        # allocated, 144 / 151 -- so the budget is taken as it is; a configuration that still spills is refused by the runtime as ever)
+        slack = 0 if info.get("stages", 1) > 1 else 24
+        return info["reg_demand"] + slack <= min(256, lane_register_budget(info["threads"]))
     return spill_probability(info, prefetch_depth_of(args)) <= SPILL_THRESHOLD
 
 
