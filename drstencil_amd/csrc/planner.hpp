@@ -130,7 +130,8 @@ inline KernelPlan make_plan(const Stencil &st, const GenOptions &o_in, const std
         if (!o.bx_set) {
             const int al = round_up((st.step - 1) * hx, mxv);
             long best = -1;
-            for (int bx : {66, 64, 34, 32}) {   // wider rows leave too few rows per workgroup (measured slower)
+            for (int bx : {66, 64, 34, 32, 68, 36}) {   // wider rows leave too few rows per workgroup (measured slower)
+                if ((bx == 68 || bx == 36) && st.step < 4) continue;      // 68 / 36: for four or more stages only (fp64: they lose 4 columns per side, 68 x 2 = 136 own 128)
                 const int ox = bx * mxv - 2 * al;
                 if (ox < 1) continue;
                 const long cost = (long)ceil_div(st.N - st.halo, ox) * bx * mxv;   // lane-columns spent on a row
@@ -138,7 +139,9 @@ inline KernelPlan make_plan(const Stencil &st, const GenOptions &o_in, const std
             }
             o.bx_set = true;
         }
-        if (!o.by_set) { o.by = std::max(1, std::min(15, 1000 / o.bx)); o.by_set = true; }
+        // four or more stages keep 3(n - 1) + ... planes of sums per lane: 12 wavefronts (<= 768 lanes, 3 per SIMD: 168 registers) hold what 16
+        // cannot (fp64, 4 stages: 151-163 VGPRs at 726 lanes, scratch at 990; profiles/r04_exp_r4o.log)
+        if (!o.by_set) { o.by = std::max(1, std::min(15, (st.step >= 4 ? 768 : 1000) / o.bx)); o.by_set = true; }
         if (!o.my_set) { o.bmy = 2; o.cmy = 1; o.my_set = true; }
         if (!o.sn_set) { o.sn = 32; o.sn_set = true; }
     }

@@ -23,8 +23,8 @@ static const TunedDefault kTunedDefaults[] = {
     {"3d", 0x6ff9ee97u, 7, 1, 2, "fp64", 0, 1024, "--bx 64 --by 16 --block-merge-x 2 --block-merge-y 2 --sn 16 --xcd-remap 2 --pin 1 --cc-opt -fno-slp-vectorize"},
     {"3d", 0x6ff9ee97u, 7, 1, 3, "fp64", 1, 512, "--skew 2 --pin 1 --exact-y 1 --prefetch --bx 66 --by 15 --block-merge-x 2 --block-merge-y 2 --sn 64 --xcd-remap 4"},
     {"3d", 0x6ff9ee97u, 7, 1, 3, "fp64", 1, 1024, "--skew 1 --pin 1 --exact-y 1 --prefetch --bx 66 --by 15 --block-merge-x 2 --block-merge-y 2 --sn 256 --xcd-remap 4"},
-    {"3d", 0x6ff9ee97u, 7, 1, 4, "fp64", 1, 512, "--skew 1 --pin 1 --exact-y 1 --prefetch --prefetch-depth 2 --bx 66 --by 11 --block-merge-x 2 --block-merge-y 2 --sn 64 --xcd-remap 4"},
-    {"3d", 0x6ff9ee97u, 7, 1, 4, "fp64", 1, 1024, "--skew 1 --pin 1 --exact-y 1 --prefetch --prefetch-depth 2 --bx 66 --by 11 --block-merge-x 2 --block-merge-y 2 --sn 256 --xcd-remap 4"},
+    {"3d", 0x6ff9ee97u, 7, 1, 4, "fp64", 1, 512, "--skew 1 --pin 1 --exact-y 1 --prefetch --prefetch-depth 2 --bx 68 --by 11 --block-merge-x 2 --block-merge-y 2 --sn 64 --xcd-remap 4"},
+    {"3d", 0x6ff9ee97u, 7, 1, 4, "fp64", 1, 1024, "--skew 1 --pin 1 --exact-y 1 --prefetch --prefetch-depth 2 --bx 68 --by 11 --block-merge-x 2 --block-merge-y 2 --sn 256 --xcd-remap 4"},
     {"3d", 0x62e6907cu, 9, 1, 2, "fp64", 0, 512, "--schedule scatter --prefetch --prefetch-depth 1 --bx 32 --by 16 --block-merge-x 2 --block-merge-y 2 --sn 32 --xcd-remap 2 --order rows"},
 };
 static const int kTunedDefaultsCount = (int)(sizeof(kTunedDefaults) / sizeof(kTunedDefaults[0]));
