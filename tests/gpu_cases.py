@@ -39,6 +39,7 @@ _add("3d7_fp32_eager", 3, "t3_star", "--dtype", "fp32", "--lazy-rims", "0", "--p
 _add("3d7_fp32_cyclicy", 3, "t3_star", "--dtype", "fp32", "--cyclic-merge-y", "3", "--by", "2", "--bx", "32", "--sn", "9")
 _add("3d7_fp32_step2_xcd_units", 3, "t3_star", "--dtype", "fp32", "--step", "2", "--sn", "8", "--xcd-remap", "4", "--bx", "16", "--by", "4", "--block-merge-y", "2")
 _add("3d7_fp64_t3_skew", 3, "t3_star", "--dtype", "fp64", "--step", "3", "--temporal", "1", "--skew", "1", "--pin", "1", "--exact-y", "1", "--bx", "34", "--by", "8", "--block-merge-y", "2", "--sn", "16", "--xcd-remap", "4")
+_add("3d7_fp64_t4_auto", 3, "t3_star", "--dtype", "fp64", "--step", "4", "--temporal", "1", "--prefetch", "--prefetch-depth", "2", "--bx", "36", "--by", "11", "--block-merge-y", "2", "--sn", "16", "--xcd-remap", "4")
 _add("3d7_fp32_t2_skew_rows", 3, "t3_star", "--dtype", "fp32", "--step", "2", "--temporal", "1", "--skew", "1", "--order", "rows", "--prefetch", "--bx", "34", "--by", "8", "--block-merge-y", "2", "--sn", "16")
 # round 4: --cyclic-merge-x is the reference's strided layout (a lane's points Bx columns apart; codegen.hpp:116-141)
 _add("3d7_fp32_cyclicx", 3, "t3_star", "--dtype", "fp32", "--cyclic-merge-x", "4", "--bx", "32", "--by", "4", "--block-merge-y", "2", "--sn", "9")

@@ -211,6 +211,7 @@ EDGE = [
     ("2d_stream_temporal4_skew_fwd", 2, "STAR2", (1, 40, 270), ["--dtype", "fp64", "--streaming", "--sn", "7", "--step", "4", "--temporal", "1", "--skew", "1", "--prefetch"]),
     ("3d_temporal3_skew2_taps_fwd", 3, "STAR3", (15, 19, 140), ["--3d", "--dtype", "fp64", "--sn", "4", "--step", "3", "--temporal", "1", "--skew", "2", "--prefetch", "--pin", "1", "--exact-y", "1", "--bx", "34", "--by", "8", "--block-merge-y", "2"]),
     ("3d_temporal3_skew2_sn1_fwd", 3, "STAR3", (13, 17, 70), ["--3d", "--dtype", "fp64", "--step", "3", "--temporal", "1", "--skew", "2", "--bx", "18", "--by", "8", "--block-merge-y", "2", "--sn", "1", "--prefetch"]),
+    ("3d_temporal4_auto_pd2_fwd", 3, "STAR3", (21, 30, 150), ["--3d", "--dtype", "fp64", "--sn", "8", "--step", "4", "--temporal", "1", "--prefetch", "--prefetch-depth", "2", "--bx", "20", "--by", "11", "--block-merge-y", "2"]),
     ("2d_stream_temporal4_skew2_fwd", 2, "STAR2", (1, 40, 270), ["--dtype", "fp64", "--streaming", "--sn", "7", "--step", "4", "--temporal", "1", "--skew", "2", "--prefetch", "--order", "rows"]),
     ("3d_temporal2_window_loads", 3, "STAR3", (17, 21, 300), ["--3d", "--dtype", "fp64", "--sn", "6", "--step", "2", "--temporal", "1", "--prefetch", "--prefetch-depth", "2", "--by", "8", "--block-merge-y", "2", "--uniform-loads", "2", "--drain", "1"]),
 ]
@@ -253,6 +254,9 @@ RACE = [
     ("3d_temporal3_skew2_taps", 3, "STAR3", (15, 19, 140), ["--3d", "--dtype", "fp64", "--sn", "4", "--step", "3", "--temporal", "1", "--skew", "2", "--prefetch", "--pin", "1", "--exact-y", "1", "--bx", "34", "--by", "8", "--block-merge-y", "2"]),
     ("3d_temporal3_skew2_rows", 3, "STAR3", (17, 21, 300), ["--3d", "--dtype", "fp64", "--sn", "6", "--step", "3", "--temporal", "1", "--skew", "2", "--prefetch", "--order", "rows", "--bx", "18", "--by", "8", "--block-merge-y", "2"]),
     ("3d_temporal2_skew2_pd2_lds", 3, "STAR3", (17, 21, 300), ["--3d", "--dtype", "fp64", "--sn", "6", "--step", "2", "--temporal", "1", "--skew", "2", "--prefetch", "--prefetch-depth", "2", "--xrim", "lds", "--by", "8", "--block-merge-y", "2"]),
+    # the shipped 4-stage geometry in small: 11-row workgroups, depth-2 prefetch, skew / pin / exact-y left to the generator (on for >= 3 stages)
+    ("3d_temporal4_auto_pd2", 3, "STAR3", (21, 30, 150), ["--3d", "--dtype", "fp64", "--sn", "8", "--step", "4", "--temporal", "1", "--prefetch", "--prefetch-depth", "2", "--bx", "20", "--by", "11", "--block-merge-y", "2"]),
+    ("3d_temporal4_default_geometry", 3, "STAR3", (9, 40, 290), ["--3d", "--dtype", "fp64", "--sn", "5", "--step", "4", "--temporal", "1"]),
     ("2d_stream_temporal4_skew2", 2, "STAR2", (1, 40, 270), ["--dtype", "fp64", "--streaming", "--sn", "7", "--step", "4", "--temporal", "1", "--skew", "2", "--prefetch"]),
     ("2d25_stream_temporal2_skew2", 2, "BOX25", (1, 61, 268), ["--dtype", "fp64", "--streaming", "--sn", "9", "--step", "2", "--temporal", "1", "--skew", "2", "--prefetch", "--xrim", "lds"]),
     ("3d_temporal3_lds", 3, "STAR3", (15, 19, 140), ["--3d", "--dtype", "fp64", "--sn", "4", "--step", "3", "--temporal", "1", "--xrim", "lds", "--bx", "34", "--by", "8", "--block-merge-y", "2"]),
