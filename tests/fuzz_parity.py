@@ -89,7 +89,9 @@ def make_jobs(n, seed):
         stc = os.path.join(ROOT, "tests", "stc", name + ".stc")
         for dtype in ("fp32", "fp64"):
             t.order, t.ndim, t.elem_bytes = order, ndim, 4 if dtype == "fp32" else 8
-            space = t.enumerate_space((1, 2, 3) if order == 1 else (1, 2))
+            # FUZZ_STEPS="3,4" FUZZ_SPACE_R4=1: the deep pipelines of round 4 (4 on-chip stages; 11-row workgroups, 36 / 68-lane rows, sn 128 / 256)
+            steps = tuple(int(x) for x in os.environ.get("FUZZ_STEPS", "1,2,3").split(","))
+            space = t.enumerate_space(steps if order == 1 else tuple(x for x in steps if x <= 2) or (2,), round4=bool(os.environ.get("FUZZ_SPACE_R4")))
             for v in random.sample(space, min(len(space), max(1, n // (2 * len(STCS))))):
                 cl = t.cfgToCommandLine(v).split()
                 if "cross" in name:
