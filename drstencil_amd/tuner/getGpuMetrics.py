@@ -11,7 +11,8 @@ Round 4: the "why" columns beside each winner (compile_run.sh's tcc / sq / sq2 /
 row: L2 Hit Rate (its "L2 Hit Rate"), Effective Clock (its "SM Frequency": GRBM_GUI_ACTIVE / 8 XCDs / the dispatch's own duration),
 Waves Waiting and Issue Stalled (its "No Eligible" / "Warp Cycles Per Issued Instruction"), Issue Busy ("Issue Slots Busy"), LDS Bank
 Conflicts ("Mem Pipes Busy" has no closer twin), the instruction mix ("Executed Instructions", "Branch Instructions"), VALU Busy ("SM Busy"),
-Waves and Occupancy ("Waves Per SM", "Theoretical Occupancy").  A pass that did not run leaves its cells empty."""
+Waves and Occupancy ("Waves Per SM", "Theoretical Occupancy"), and the launch-limit family (launch_limits below).  A pass that did
+not run leaves its cells empty."""
 import csv
 import glob
 import os
@@ -25,12 +26,18 @@ HEADER = ["Metric Name", "Duration", "Calls", "FETCH_SIZE", "WRITE_SIZE", "HBM T
           "VALU Instructions", "VMEM Read Instructions", "VMEM Write Instructions", "LDS Instructions", "SALU Instructions", "Branch Instructions",
           "Waves", "Occupancy",
           # ... and figures derived from the above, named after the reference's columns where one exists
-          "Memory Throughput", "Read Throughput", "Write Throughput", "Elapsed Cycles", "Executed Instructions", "Executed Ipc Elapsed", "Waves Per CU", "Threads"]
+          "Memory Throughput", "Read Throughput", "Write Throughput", "Elapsed Cycles", "Executed Instructions", "Executed Ipc Elapsed", "Waves Per CU", "Threads",
+          # ... the launch-limit family of the reference's row ("Block Limit Registers / Shared Mem / Warps", "Theoretical Active Warps per SM",
+          # "Theoretical Occupancy", "Achieved Active Warps Per SM", "Achieved Occupancy"): what caps the resident workgroups of a CU
+          # (512 VGPRs per SIMD lane in granules of 8, 160 KiB of LDS, 32 wave slots), and what the counters saw
+          "Waves Per Workgroup", "Block Limit Registers", "Block Limit LDS", "Block Limit Waves", "Theoretical Active Waves Per CU", "Theoretical Occupancy",
+          "Achieved Active Waves Per CU", "Achieved Occupancy", "Wave Lifetime"]
 UNITS = ["", "nsecond", "", "KiB", "KiB", "byte", "byte", "GB/s", "of 8 TB/s", "", "", "", "byte", "", "", "ms", "", "", "byte/lane", "",
          "", "of L2 requests", "GHz", "of wave cycles", "of wave cycles", "of wave cycles", "of LDS cycles", "of wave cycles",
          "wave instructions", "wave instructions", "wave instructions", "wave instructions", "wave instructions", "wave instructions",
          "", "waves/SIMD",
-         "GB/s (HBM, counters)", "GB/s", "GB/s", "cycle (busy, per XCD)", "wave instructions", "wave instructions / cycle / CU", "", ""]
+         "GB/s (HBM, counters)", "GB/s", "GB/s", "cycle (busy, per XCD)", "wave instructions", "wave instructions / cycle / CU", "", "",
+         "", "workgroups/CU", "workgroups/CU", "workgroups/CU", "", "of 32 wave slots", "", "of 32 wave slots", "of the launch"]
 
 
 def _one(pattern):
@@ -42,6 +49,28 @@ def _dr_rows(path):
     if not path:
         return []
     return [r for r in csv.DictReader(open(path)) if r.get("Kernel_Name", r.get("Name", "")).startswith("dr_")]
+
+
+def launch_limits(wg, vgprs, agprs, lds, vals, cycles):
+    """Resident workgroups per CU by resource, the occupancy they allow, and the occupancy the counters saw: SQ_WAVE_CYCLES counts
+    resident waves in units of four cycles, so 4 x SQ_WAVE_CYCLES / (busy cycles x 256 CUs) is the average number of waves a CU held, and
+    the same figure over SQ_WAVES and the cycles of the launch is how much of the launch one wave lived (1/2 = two rounds of workgroups)."""
+    try:
+        wpw = -(-int(wg) // 64)
+    except ValueError:
+        return [""] * 9
+    regs = -(-(int(vgprs or 0) + int(agprs or 0)) // 8) * 8
+    by_regs = (min(8, 512 // regs) * 4) // wpw if regs else ""
+    by_lds = (160 * 1024) // int(lds) if str(lds).isdigit() and int(lds) > 0 else ""
+    by_waves = 32 // wpw
+    limit = min(x for x in (by_regs, by_lds, by_waves) if x != "")
+    out = [wpw, by_regs, by_lds, by_waves, limit * wpw, limit * wpw / 32.0]
+    if "SQ_WAVE_CYCLES" in vals and cycles:
+        act = 4.0 * vals["SQ_WAVE_CYCLES"] / (cycles * 256.0)
+        out += [act, act / 32.0, 4.0 * vals["SQ_WAVE_CYCLES"] / vals["SQ_WAVES"] / cycles if vals.get("SQ_WAVES") else ""]
+    else:
+        out += ["", "", ""]
+    return out
 
 
 def main(name=""):
@@ -103,6 +132,7 @@ def main(name=""):
     why += [traffic / dur if traffic == traffic and dur == dur and dur > 0 else "", fetch * 2048 / dur if fetch == fetch and dur == dur and dur > 0 else "",
             write * 1024 / dur if write == write and dur == dur and dur > 0 else "", cycles if cycles else "", sum(insts) if insts else "",
             sum(insts) / cycles / 256.0 if insts and cycles else "", vals["SQ_WAVES"] / 256.0 if "SQ_WAVES" in vals else "", threads]
+    why += launch_limits(meta.get("Workgroup_Size", ""), _rep("VGPRs:"), _rep("AGPRs:"), meta.get("LDS_Block_Size", ""), vals, cycles)
     row = [name, dur, calls, fetch, write, traffic, alg, gbs, gbs / 8000.0, interior * mac.get("Step", 1) / dur if dur == dur and dur > 0 else float("nan"),
            meta.get("Grid_Size", ""), meta.get("Workgroup_Size", ""), meta.get("LDS_Block_Size", ""), meta.get("VGPR_Count", ""), meta.get("SGPR_Count", ""),
            t.group(1) if t else "", rms.group(1) if rms else "", _rep("AGPRs:"), _rep("ScratchSize [bytes/lane]:"), _rep("VGPRs Spill:")] + why

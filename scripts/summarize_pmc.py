@@ -106,6 +106,11 @@ if "TCC_HIT_sum" in out:
     out["l2_hit_rate"] = out["TCC_HIT_sum"] / (out["TCC_HIT_sum"] + out["TCC_MISS_sum"])
 if "SQ_WAIT_ANY" in out and "SQ_WAVE_CYCLES" in out:
     out["wait_any_frac"] = out["SQ_WAIT_ANY"] / out["SQ_WAVE_CYCLES"]
+if "SQ_WAVE_CYCLES" in out and out.get("GRBM_GUI_ACTIVE") and out.get("SQ_WAVES"):
+    # SQ_WAVE_CYCLES counts resident waves in units of four cycles: the average number of waves a CU held, and the share of the launch
+    # one wave lived (1/2: the grid ran as two rounds of workgroups)
+    out["achieved_waves_per_cu"] = 4.0 * out["SQ_WAVE_CYCLES"] / (out["GRBM_GUI_ACTIVE"] / 8.0 * 256.0)
+    out["wave_lifetime_frac"] = 4.0 * out["SQ_WAVE_CYCLES"] / out["SQ_WAVES"] / (out["GRBM_GUI_ACTIVE"] / 8.0)
 if "SQ_LDS_BANK_CONFLICT" in out:
     out["lds_conflict_frac"] = out["SQ_LDS_BANK_CONFLICT"] / max(out["SQ_LDS_IDX_ACTIVE"], 1)
 if "TCC_EA0_RDREQ_LEVEL_sum" in out and out.get("TCC_EA0_RDREQ_sum"):
@@ -113,5 +118,6 @@ if "TCC_EA0_RDREQ_LEVEL_sum" in out and out.get("TCC_EA0_RDREQ_sum"):
     out["ea_write_latency_cycles"] = out["TCC_EA0_WRREQ_LEVEL_sum"] / max(out["TCC_EA0_WRREQ_sum"], 1)
 json.dump(out, open(os.path.join("gpurun_out", tag + "_counters.json"), "w"), indent=1)
 keys = ("kernel", "timed_avg_ns", "timed_min_ns", "timed_median_ns", "bench_avg_launch_ms_same_run_hip_events", "timed_avg_over_hip_events", "traffic_over_algorithmic", "l2_hit_rate",
-        "wait_any_frac", "lds_conflict_frac", "effective_clock_GHz_grbm_pass", "grbm_pass_launch_ns", "effective_clock_GHz_vs_trace_pass", "ea_read_latency_cycles", "ea_write_latency_cycles", "vgpr")
+        "wait_any_frac", "lds_conflict_frac", "effective_clock_GHz_grbm_pass", "grbm_pass_launch_ns", "effective_clock_GHz_vs_trace_pass", "ea_read_latency_cycles", "ea_write_latency_cycles", "vgpr",
+        "achieved_waves_per_cu", "wave_lifetime_frac")
 print(json.dumps({k: out[k] for k in keys if k in out}))

@@ -396,3 +396,26 @@ def test_gpus_option_emits_an_n_gpu_host():
     rc2d, _, two = drs.generate(["--dtype", "fp64", "--gpus", "2", os.path.join(ROOT, "tests", "stc", "t2_star.stc")])
     assert rc2d == 0 and "const long DIM0 = M;" in two and "const size_t plane = (size_t)N;" in two and "#if 0\n    if (!rh) {" in two
     assert drs.generate(base + ["--gpus", "0", stc])[0] == 255 and drs.generate(base + ["--gpus", "65", stc])[0] == 255
+
+
+def test_metrics_launch_limit_family():
+    """getGpuMetrics.py's launch-limit columns (the reference's "Block Limit ...", "Theoretical / Achieved Occupancy": getGpuMetrics.py:9)
+    on the committed counters of three bench kernels (profiles/r04h_*_counters.json: VGPRs from the compiler report)."""
+    import json
+    from drstencil_amd.tuner import getGpuMetrics as g
+    def counters(name):
+        d = json.load(open(os.path.join(ROOT, "profiles", name)))
+        return {k: d[k] for k in ("SQ_WAVE_CYCLES", "SQ_WAVES")}, d["GRBM_GUI_ACTIVE"] / 8.0, d
+    # C4 headline: 1024 lanes, 95 VGPRs, 76 KiB of LDS: one workgroup per CU by registers (5 waves per SIMD < 2 x 4), two by LDS and waves
+    vals, cycles, d = counters("r04h_c4_headline_counters.json")
+    out = g.launch_limits(d["wg"], "95", "0", d["lds"], vals, cycles)
+    assert out[:6] == [16, 1, 2, 2, 16, 0.5] and 15.0 < out[6] <= 16.0 and 0.028 < out[8] < 0.034, out      # 8192 workgroups, one per CU: 32 rounds
+    # C3 headline: 512 lanes, 204 VGPRs: 8 resident waves per CU, and the 512 workgroups run as two rounds of 256 (a wave lives half the launch)
+    vals, cycles, d = counters("r04h_c3_headline_counters.json")
+    out = g.launch_limits(d["wg"], "204", "0", d["lds"], vals, cycles)
+    assert out[:6] == [8, 1, 4, 4, 8, 0.25] and 7.0 < out[6] <= 8.0 and 0.4 < out[8] < 0.55, out
+    # 4-stage pipeline: 748 lanes = 12 waves, 163 VGPRs (3 waves per SIMD)
+    vals, cycles, d = counters("r04h_c4f64_temporal4_counters.json")
+    out = g.launch_limits(d["wg"], "163", "0", d["lds"], vals, cycles)
+    assert out[:5] == [12, 1, 1, 2, 12] and 11.0 < out[6] <= 12.0 and 0.11 < out[8] < 0.13, out      # 2048 workgroups: 8 rounds
+    assert g.launch_limits("", "", "", "", {}, None) == [""] * 9 and len(g.HEADER) == len(g.UNITS) == 53

@@ -422,6 +422,8 @@ def _check_why_columns(rec):
     assert 0.0 <= float(rec["Waves Waiting"]) <= 1.0 and 0.0 <= float(rec["Issue Stalled"]) <= 1.0 and 0.0 <= float(rec["LDS Bank Conflicts"]) <= 1.0, rec
     assert float(rec["VALU Instructions"]) > 0 and float(rec["VMEM Read Instructions"]) > 0 and float(rec["VMEM Write Instructions"]) > 0 and float(rec["LDS Instructions"]) > 0, rec
     assert float(rec["Waves"]) > 0 and 1 <= int(rec["Occupancy"]) <= 8 and float(rec["Traffic / Algorithmic"]) >= 0, rec
+    assert 1 <= int(rec["Block Limit Waves"]) <= 32 and int(rec["Block Limit Registers"]) >= 1 and int(rec["Block Limit LDS"]) >= 1, rec
+    assert 0.0 < float(rec["Theoretical Occupancy"]) <= 1.0 and 0.0 < float(rec["Achieved Active Waves Per CU"]) <= 32.0 and 0.0 < float(rec["Wave Lifetime"]) <= 1.5, rec
 
 
 def test_reference_style_profile_flow():
