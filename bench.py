@@ -749,10 +749,28 @@ def main(argv=None):
             else:
                 n1, ms1 = k.run_timed(A.data_ptr(), B.data_ptr(), iterations=iters, warmup=4, stream=stream.cuda_stream)
             by = k.bytes_per_launch()
-            return {"generator_options": " ".join(o), "step": k.info["step"], "arithmetic": k.info.get("arithmetic"), "tolerance_horizon_iterations": k.info.get("tolerance_horizon_iterations"),
+            out_ = {"generator_options": " ".join(o), "step": k.info["step"], "arithmetic": k.info.get("arithmetic"), "tolerance_horizon_iterations": k.info.get("tolerance_horizon_iterations"),
                     "GStencil_per_s": k.updates_per_launch() * n1 / (ms1 * 1e-3) / 1e9,
                     "avg_launch_ms": ms1 / n1, "achieved_GBps": by * n1 / (ms1 * 1e-3) / 1e9,
                     "roofline_frac": by * n1 / (ms1 * 1e-3) / 1e9 / HBM_PEAK_GBS}
+            if not args.no_verify:
+                # no number without a check in the same run: ONE launch on the pristine input against the emitted gold kernel, whole grid -- bit for
+                # bit, or within the tolerance for a re-associated pipeline (the oracle-slab check is the headline's and the 3- / 4-stage pipelines';
+                # every side kernel is also a full-size parity case of the GPU suite, tests/gpu_cases.py FULL)
+                G_ = torch.zeros_like(A)
+                A.copy_(R); B.zero_()
+                k.launch(A.data_ptr(), B.data_ptr())
+                k.launch_gold(A.data_ptr(), G_.data_ptr())
+                torch.cuda.synchronize()
+                if k.info.get("arithmetic") == "reassociated":
+                    h_ = k.info["halo"]
+                    inner_ = tuple(slice(h_, d_ - h_) for d_ in A.shape)
+                    rel_ = float(((B[inner_] - G_[inner_]).abs() / G_[inner_].abs().clamp_min(1e-30)).max())
+                    out_["verified_vs_gold_kernel_full_grid"] = {"ok": bool(rel_ <= (1e-6 if w["dtype"] == "fp32" else 1e-12)), "max_rel": rel_, "bit_exact_required": False}
+                else:
+                    out_["verified_vs_gold_kernel_full_grid"] = {"ok": bool(torch.equal(B, G_)), "bit_exact_required": True}
+                del G_
+            return out_
         step1 = side(kern1, STEP1[args.workload], 16) if kern1 is not None else None
         fused2 = side(kernf, TEMPORAL2[args.workload], 32) if kernf is not None else None
         window2 = side(kernw, WINDOW2WG[args.workload], 32) if kernw is not None else None
@@ -1029,6 +1047,9 @@ def main(argv=None):
         if prev_headline is not None:
             out["rounds_1_to_3_headline_kernel"] = prev_headline    # 32 x 16 lanes, 32-plane blocks, prefetch depth 3 (204 VGPRs)
         out["two_workgroups_per_cu_kernel"] = window2   # the same fused arithmetic from rotating register windows at 126 VGPRs: two workgroups per CU
+        sides_ = [v_ for v_ in (step1, fused2, window2, prev_headline, fused3) + tuple(temporals.values()) if v_ and "verified_vs_gold_kernel_full_grid" in v_]
+        if sides_:
+            out["side_kernels_verified"] = all(v_["verified_vs_gold_kernel_full_grid"]["ok"] for v_ in sides_)
         if not args.no_cpu_baseline and pworld == 1:
             sys.path.insert(0, ROOT)
             out["cpu_baseline"], oracle_check = cpu_baseline(args.workload, step, host_slab=host_slab, gpu_first_launch=first_out, temporal=kinfo.get("stages", 1) > 1)

@@ -9,7 +9,7 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag = sys.argv[1] if len(sys.argv) > 1 else "r04"
 order = ["c4", "c3", "c2", "c5", "c2f64", "c3f64", "c4f64", "s_2d5pt_star", "s_2d5pt_cross", "s_2d9pt_box", "s_2d9pt_star", "s_2d9pt_cross", "s_2d25pt_box", "s_3d9pt_cross"]
-rows = ["| workload | headline kernel (generator options after the problem's) | launch | GStencil/s | frac of 8 TB/s | traffic / algorithmic | side measurements (same run, verified) |", "|---|---|---|---|---|---|---|"]
+rows = ["| workload | headline kernel (generator options after the problem's) | launch | GStencil/s | frac of 8 TB/s | traffic / algorithmic | side measurements (same run, each checked against its gold kernel on the whole grid) |", "|---|---|---|---|---|---|---|"]
 for w in order:
     p = os.path.join(ROOT, "profiles", "%s_bench_%s.json" % (tag, w))
     if not os.path.exists(p):
