@@ -8,7 +8,7 @@ static const TunedDefault kTunedDefaults[] = {
     {"2d", 0xe818b6ceu, 5, 1, 1, "fp32", 0, 8192, "--bx 128 --by 2 --block-merge-x 4 --block-merge-y 2 --xcd-remap 0"},
     {"2d", 0xe818b6ceu, 5, 1, 1, "fp64", 0, 8192, "--bx 128 --by 4 --block-merge-x 2 --block-merge-y 2 --xcd-remap 0"},
     {"2d", 0xe818b6ceu, 5, 1, 2, "fp64", 0, 8192, "--bx 128 --by 4 --block-merge-x 2 --block-merge-y 2 --xcd-remap 0"},
-    {"2d", 0x610f3e78u, 9, 1, 2, "fp64", 0, 8192, "--bx 64 --by 4 --block-merge-x 2 --block-merge-y 4 --xcd-remap 0"},
+    {"2d", 0x610f3e78u, 9, 1, 2, "fp64", 0, 8192, "--bx 64 --by 4 --block-merge-x 2 --block-merge-y 6 --xcd-remap 0"},
     {"2d", 0x694374dcu, 9, 2, 2, "fp64", 0, 8192, "--bx 64 --by 4 --block-merge-x 2 --block-merge-y 4 --xcd-remap 0 --order rows"},
     {"2d", 0x7546f2ecu, 9, 2, 2, "fp64", 0, 8192, "--bx 64 --by 4 --block-merge-x 2 --block-merge-y 4 --xcd-remap 0 --order rows"},
     {"2d", 0x4e1e9130u, 25, 2, 1, "fp64", 0, 16384, "--bx 64 --by 4 --block-merge-x 2 --block-merge-y 8 --xcd-remap 0 --order rows"},
