@@ -453,6 +453,10 @@ def searchSpace(stc, is3d, dtype, configs, outdir, iterations=8, budget_s=None, 
     pool = ProcessPoolExecutor(max_workers=jobs, mp_context=multiprocessing.get_context("forkserver"))
     list(pool.map(_noop, range(jobs)))             # start the fork server and the workers now, before HIP is up
     futures = [pool.submit(_build, j) for j in jobsl]
+    if os.environ.get("DRS_TUNE_BUILD_ONLY"):        # fill the kernel cache on a machine without a GPU; the run on the GPU box then finds every kernel built
+        built = sum(1 for f in futures if f.result()[1])
+        print("built {0} of {1} kernels in {2:.0f} s".format(built, len(jobsl), time.time() - t_start), flush=True)
+        return []
 
     import drstencil_amd as drs
     torch = None
