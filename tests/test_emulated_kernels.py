@@ -344,7 +344,12 @@ def _emulated_fuzz_jobs(n=14, seed=9):
     for ndim, pts, dims, order in [(3, "STAR3", (13, 21, 300), 1), (2, "STAR2", (1, 37, 300), 1), (2, "BOX25", (1, 29, 280), 2)]:
         for dtype in ("fp32", "fp64"):
             t.order, t.ndim, t.elem_bytes = order, ndim, 4 if dtype == "fp32" else 8
-            space = [v for v in t.enumerate_space((1, 2)) if v[2][0] * v[2][1] <= 256 and v[2][0] <= 66 and v[3] <= 16]
+            # fuzz_emulated.py with FUZZ_STEPS="2,3,4" FUZZ_SPACE_R4=1: deep pipelines and the round-4 space (the pytest sample keeps steps 1-2)
+            steps_ = tuple(int(x) for x in os.environ.get("FUZZ_STEPS", "1,2").split(","))
+            if order > 1:
+                steps_ = tuple(x for x in steps_ if x <= 2) or (2,)
+            lanes_ = 768 if os.environ.get("FUZZ_SPACE_R4") else 256
+            space = [v for v in t.enumerate_space(steps_, round4=bool(os.environ.get("FUZZ_SPACE_R4"))) if v[2][0] * v[2][1] <= lanes_ and v[2][0] <= 68 and v[3] <= 16]
             for v in rnd.sample(space, min(len(space), max(1, n // 6))):
                 cl = t.cfgToCommandLine(v).split()
                 if "--prefetch-depth" in cl:

@@ -201,6 +201,47 @@ def test_c1_full_size_100_iterations_vs_oracle(torch_cuda):
     assert oracle.check(spec, A, A_nc)["max_rel"] <= 2e-6
 
 
+def _whole_grid_cases():
+    import bench
+    out = []
+    for c, f in (("c3", "c3f64"), ("c4", "c4f64")):
+        out += [(c + "_headline", c, bench.TUNED[c]), (c + "_fused_step3", c, bench.FUSED3[c][0]), (c + "_step1", c, bench.STEP1[c]),
+                (f + "_headline", f, bench.TUNED[f]), (f + "_temporal3", f, bench.TEMPORAL3[f]), (f + "_temporal4", f, bench.TEMPORAL4[f])]
+    return out
+
+
+@pytest.mark.parametrize("cid,workload,opts", _whole_grid_cases(), ids=[c[0] for c in _whole_grid_cases()])
+def test_3d7pt_whole_grid_vs_oracle(torch_cuda, cid, workload, opts):
+    """BASELINE configs C3 and C4 (3d7pt_star 512^3 and 1024^3, fp32 and the reference's fp64) against the CPU oracle on the WHOLE grid, the
+    spec's own loop (iterations 4): the kernels bench.py times -- the step-1 / fused step-2 / fused step-3 kernels bit for bit, the 3- and
+    4-stage pipelines within 1e-12 of the oracle's fused --step n arithmetic.  Beyond the three slabs of test_full_size_properties: no plane
+    and no byte offset past 2^32 is left to the gold kernel alone.  Host memory: up to 35 GB at 1024^3 fp64 (the GPU boxes allow 300)."""
+    import bench
+    import drstencil_amd as drs
+    torch = torch_cuda
+    w = bench.WORKLOADS[workload]
+    kern = drs.Kernel(list(opts) + [w["stc"]])
+    step = _step(opts)
+    spec = oracle.Spec(w["stc"], 3, step)
+    dt = np.float32 if w["dtype"] == "fp32" else np.float64
+    A0 = oracle.fill_random(spec.shape, dt)
+    A_ref, B_ref = A0.copy(), np.zeros_like(A0)
+    n_ref = oracle.run(spec, A_ref, B_ref, contract=1)
+    n, A, B = run_hip(torch, kern, A0, np.zeros_like(A0))
+    del A0
+    assert n == n_ref == spec.launches
+    if kern.info.get("arithmetic") == "reassociated":
+        assert kern.info["stages"] == step and w["dtype"] == "fp64"
+        ma, mb = oracle.check(spec, A, A_ref), oracle.check(spec, B, B_ref)
+        assert ma["max_rel"] <= 1e-12 and mb["max_rel"] <= 1e-12, (cid, ma, mb)
+        h = spec.halo
+        ring = np.ones(A.shape, bool)
+        ring[tuple(slice(h, s - h) for s in A.shape)] = False
+        assert np.array_equal(A[ring], A_ref[ring]) and np.array_equal(B[ring], B_ref[ring])
+    else:
+        assert np.array_equal(A, A_ref) and np.array_equal(B, B_ref), cid
+
+
 def test_temporal_blocking_margin_over_100_iterations(torch_cuda):
     """Where does 1e-6 break for temporal blocking, and does the product stay on the right side of it?  On-chip time steps
     re-associate the fused sum.  On a spec that asks for 100 iterations:
