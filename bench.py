@@ -401,7 +401,33 @@ def slab_verify_view(dim0, H, launches, world, rank):
     return max(0, z0 - launches * H), min(dim0, z1 + launches * H)
 
 
-def verify_slab_run(torch, dist, run, sweep, dims, H, launches, iters, rank, world, dev, tdt):
+def oracle_check_slab_run(torch, run, workload, step, dims, H, launches, n, rank, world, tdt):
+    """The CPU oracle as the checker of an N > 1 run (the checker half of the CPU leg; nothing is timed here): this rank's own planes after the
+    exchanged run against `n` oracle sweeps of the same seeded global grid on [z0 - launches*H, z1 + launches*H) -- wide enough that the planes
+    the rank owns cannot be reached from the cut faces.  Bit for bit (the slab kernels are the fused gold-order headline).  136 planes of 1024^2
+    per rank at N = 8: a fraction of a second on the node's cores, shared out between the ranks."""
+    import numpy as np
+    import oracle
+    w = WORKLOADS[workload]
+    p = run.plan
+    lo, hi = slab_verify_view(dims[0], H, launches, world, rank)
+    A = _seeded_planes(torch, lo, hi, tuple(dims[1:]), tdt, run.A.device).cpu().numpy()
+    B = np.zeros_like(A)
+    oracle.set_threads(max(1, min(oracle.threads(), oracle.usable_cpus() // max(1, world))))
+    cs = oracle.Spec(w["stc"], w["ndim"], step)
+    if w["ndim"] == 3:
+        cs.set_dims(hi - lo, dims[1], dims[2])
+    else:
+        cs.set_dims(1, hi - lo, dims[1])
+    for _ in range(n // 2):
+        oracle.sweep(cs, A, B, contract=1)
+        oracle.sweep(cs, B, A, contract=1)
+    okA = bool(np.array_equal(run.owned(run.A).cpu().numpy(), A[p.z0 - lo:p.z1 - lo]))
+    okB = bool(np.array_equal(run.owned(run.B).cpu().numpy(), B[p.z0 - lo:p.z1 - lo]))
+    return okA and okB
+
+
+def verify_slab_run(torch, dist, run, sweep, dims, H, launches, iters, rank, world, dev, tdt, workload=None, step=None):
     """N > 1: is the decomposed run (slab views, boundary / interior / pair kernels, RCCL halo exchange over xGMI) the
     single-domain run?  Every rank fills its slab with seeded planes of the GLOBAL grid, runs the reference's loop through
     SlabRun (with exchange), then recomputes the same launches on a wider slab of the same global grid with plain launches
@@ -427,11 +453,23 @@ def verify_slab_run(torch, dist, run, sweep, dims, H, launches, iters, rank, wor
     sync()
     okA = torch.equal(run.owned(run.A), A[p.z0 - lo:p.z1 - lo])
     okB = torch.equal(run.owned(run.B), B[p.z0 - lo:p.z1 - lo])
+    del A, B
+    # ... and against the CPU oracle (GPU runs of a named workload): the same planes, the same seeded grid, `n` oracle sweeps.  A rank whose
+    # oracle cannot be loaded or runs out of host memory reports that (ok: None) and the verdict rests on the comparison above
+    ok_oracle, oracle_note = None, "not run (CPU tensors / no workload named)"
+    if gpu and workload is not None and not os.environ.get("DRS_BENCH_NO_SLAB_ORACLE"):
+        try:
+            sys.path.insert(0, ROOT)
+            ok_oracle, oracle_note = oracle_check_slab_run(torch, run, workload, step, dims, H, launches, n, rank, world, tdt), "own planes == %d oracle sweeps of the same slab" % n
+        except Exception as e:       # the checker must not take the run down
+            ok_oracle, oracle_note = None, "oracle check failed to run on rank %d: %r" % (rank, e)
     from drstencil_amd.multigpu import coll_device
-    flag = torch.tensor([1 if (okA and okB) else 0], dtype=torch.int32, device=coll_device(torch, dist, dev))
+    mine = bool(okA and okB and ok_oracle is not False)
+    flag = torch.tensor([1 if mine else 0, 1 if ok_oracle else 0], dtype=torch.int32, device=coll_device(torch, dist, dev))
     dist.all_reduce(flag, op=dist.ReduceOp.MIN)
     return bool(int(flag[0])), {"decomposed_vs_single_domain": {"ok": bool(int(flag[0])), "this_rank_ok": bool(okA and okB), "launches": n, "bit_exact_required": True,
-                                                                "how": "own planes of the exchanged run == plain launches on [z0 - %d, z1 + %d) of the same seeded global grid" % (launches * H, launches * H)}}
+                                                                "how": "own planes of the exchanged run == plain launches on [z0 - %d, z1 + %d) of the same seeded global grid" % (launches * H, launches * H)},
+                                "vs_cpu_oracle_own_planes": {"ok_on_every_rank": bool(int(flag[1])), "this_rank_ok": ok_oracle, "note": oracle_note, "bit_exact_required": True}}
 
 
 def device_info(torch, dev):
@@ -999,7 +1037,8 @@ def main(argv=None):
         temporals = {}
         verified, verification, host_slab, first_out = None, None, None, None     # the slab kernels' parity is tests/test_gpu_parity.py::test_c4_slab_views_at_full_size
         if not args.no_verify and not rehearse:      # (a rehearsal's self-neighbour exchange is not the physical one)
-            verified, verification = verify_slab_run(torch, dist, run, sweep, (L, M, N) if w["ndim"] == 3 else (M, N), H, launches_per_step, iters, prank, pworld, dev, tdt)
+            verified, verification = verify_slab_run(torch, dist, run, sweep, (L, M, N) if w["ndim"] == 3 else (M, N), H, launches_per_step, iters, prank, pworld, dev, tdt,
+                                                     workload=None if args.kernel_args else args.workload, step=step)
 
     if rank == 0:
         total_launches = launches_per_step * args.steps
