@@ -588,6 +588,12 @@ def main(argv=None):
     if not args.prebuild_only and not rehearse and world != args.gpus:       # decided before anything touches the GPU
         raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
 
+    if world > 1 and not args.prebuild_only:
+        # a rank that is still here after --rank-timeout seconds (a collective that never completes on a fabric this code has not met) says where
+        # it is stuck and exits, instead of hanging until somebody else's clock runs out: a C-level watchdog thread, so it fires inside a blocked
+        # RCCL / HIP call too.  (Started as a plain command, the launcher's own deadline in spawn_ranks fires first.)
+        import faulthandler
+        faulthandler.dump_traceback_later(max(30.0, args.rank_timeout + 30.0), exit=True, file=sys.stderr)
     # stdout carries exactly ONE line, the result: RCCL prints a version banner on stdout when its first communicator comes up
     # (rank 0, five lines), and libraries may print more -- so from here on file descriptor 1 is stderr, and the JSON line goes
     # to the saved descriptor at the end
@@ -1124,6 +1130,9 @@ def main(argv=None):
         os.write(result_fd, (json.dumps(out) + "\n").encode())
     if dist is not None:
         dist.destroy_process_group()
+    if world > 1:
+        import faulthandler
+        faulthandler.cancel_dump_traceback_later()
     # a number from a kernel whose result is wrong is not a measurement: the line says "verified": false AND the exit code says so
     # (every rank holds the same AND-ed verdict of an N > 1 run; at N = 1 rank 0 folds the oracle's verdict in above)
     if (out["verified"] if rank == 0 else verified) is False:
