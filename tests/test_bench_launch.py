@@ -92,3 +92,38 @@ def test_world_size_mismatch_is_refused_before_the_gpu_is_touched(tmp_path):
     # as one rank of a launcher (WORLD_SIZE set) with a --gpus that does not match: an error, not an assert after HIP init
     r = _run(tmp_path, ["--gpus", "4"], {"WORLD_SIZE": "2", "RANK": "0"})
     assert r.returncode != 0 and "WORLD_SIZE=2" in (r.stdout + r.stderr)
+
+
+def test_oracle_slab_checker_compares_in_chunks():
+    """bench.oracle_check_slabs (the checker half of the CPU leg) on a slab thicker than one 64-slice chunk: equal output -> ok with max_rel 0;
+    one changed value in the last chunk -> not ok, and the relative error is the one planted (the whole-grid check of a 1024^3 launch walks
+    the same loop)."""
+    import numpy as np
+    sys.path.insert(0, ROOT)
+    import bench
+    import oracle
+    stc = os.path.join(ROOT, "tests", "stc", "t3_star.stc")
+    bench.WORKLOADS["_chunk_test"] = dict(stc=stc, ndim=3, dtype="fp64", name="test")
+    try:
+        spec = oracle.Spec(stc, 3, 1)
+        L, M, N = spec.dims
+        h = spec.halo
+        nsl = 70                              # two chunks: 64 + 4 output slices
+        cs = oracle.Spec(stc, 3, 1)
+        cs.set_dims(nsl, M, N)
+        src = oracle.fill_random((nsl, M, N), np.float64)
+        dst = np.zeros_like(src)
+        oracle.sweep(cs, src, dst, contract=1)
+        out = dst[h:nsl - h].copy()
+        good = bench.oracle_check_slabs("_chunk_test", 1, [{"label": "whole_grid", "z0": 0, "input": src, "output": out}], False)
+        assert good["ok"] and good["max_rel"] == 0.0 and good["slabs"][0]["slices"] == nsl
+        bad_out = out.copy()
+        bad_out[-1, h + 1, h + 2] *= 1.0 + 1e-9
+        bad = bench.oracle_check_slabs("_chunk_test", 1, [{"label": "whole_grid", "z0": 0, "input": src, "output": bad_out}], False)
+        assert not bad["ok"] and 0.5e-9 < bad["max_rel"] < 2e-9
+        tol = bench.oracle_check_slabs("_chunk_test", 1, [{"label": "whole_grid", "z0": 0, "input": src, "output": bad_out}], True)      # a pipeline's bar: 1e-12
+        assert not tol["ok"]
+        bad_out[-1, h + 1, h + 2] = out[-1, h + 1, h + 2] * (1.0 + 1e-14)
+        assert bench.oracle_check_slabs("_chunk_test", 1, [{"label": "whole_grid", "z0": 0, "input": src, "output": bad_out}], True)["ok"]
+    finally:
+        del bench.WORKLOADS["_chunk_test"]

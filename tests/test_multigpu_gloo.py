@@ -193,6 +193,13 @@ def _verify_worker(rank, world, port, step, iterations, every, break_exchange, q
                 dst[run.plan.recv_up[0]:run.plan.recv_up[1]].zero_()
         run._exchange = stale
     ok, detail = bench.verify_slab_run(torch, dist, run, sweep, (L, M, N), H, spec.launches, iterations, rank, world, torch.device("cpu"), torch.float32)
+    # the oracle-as-checker half of a GPU run's verify_slab_run (skipped above: CPU tensors), called directly: this rank's own planes after the
+    # exchanged run against oracle sweeps of the wider slab -- it must agree with the verdict above on this rank
+    bench.WORKLOADS["_gloo_test"] = dict(stc=STC, ndim=3, dtype="fp32", name="test")
+    n_launches = 2 * (-(-iterations // (2 * step)))
+    ok_oracle = bench.oracle_check_slab_run(torch, run, "_gloo_test", step, (L, M, N), H, spec.launches, n_launches, rank, world, torch.float32)
+    assert ok_oracle == detail["decomposed_vs_single_domain"]["this_rank_ok"], (rank, ok_oracle, detail)
+    assert detail["vs_cpu_oracle_own_planes"]["this_rank_ok"] is None      # not run inside verify_slab_run on CPU tensors
     q.put((rank, ok, detail["decomposed_vs_single_domain"]["this_rank_ok"]))
     dist.barrier()
     dist.destroy_process_group()
