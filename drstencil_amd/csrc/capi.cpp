@@ -87,7 +87,7 @@ void drs_free(void *p) { free(p); }
 int drs_generate(int argc, const char *const *argv, char **source, char **messages) {
     GenResult r = generate(to_args(argc, argv));
     if (source) *source = r.emitted ? dup_cstr(r.source) : nullptr;
-    if (messages) *messages = dup_cstr(r.messages);
+    if (messages) *messages = dup_cstr(r.messages + r.notes);
     return r.exit_code;
 }
 
@@ -231,7 +231,7 @@ drs_kernel *drs_kernel_build(int argc, const char *const *argv, const char *cach
     if (log) *log = nullptr;
     GenResult r = generate(to_args(argc, argv));
     if (!r.emitted) {
-        if (log) *log = dup_cstr(r.messages + (r.plan.error.empty() ? "" : ("drstencil: " + r.plan.error + "\n")));
+        if (log) *log = dup_cstr(r.messages + r.notes + (r.plan.error.empty() ? "" : ("drstencil: " + r.plan.error + "\n")));
         return nullptr;
     }
     const std::string here = self_dir();

@@ -50,6 +50,7 @@ struct GenResult {
     Stencil st;
     KernelPlan plan;
     GenOptions opt;
+    std::string notes;        // what the command prints on STDERR: remarks the reference has no counterpart for on a reference command line (stdout stays the reference's)
     std::string tuned_from;   // non-empty: the geometry / emission options came from the tuned-defaults table (this row's option string)
 };
 
@@ -316,7 +317,7 @@ inline GenResult generate(const std::vector<std::string> &args /* argv[1..] */) 
             again.push_back(args.back());
             GenResult r2 = generate(again);
             r2.tuned_from = t->options;
-            if (r2.emitted) r2.messages += std::string("drstencil: note: no geometry option given: the tuner's configuration for this stencil, step, dtype and grid size is used (") + t->options + "); --tuned-defaults 0 keeps the generic defaults\n";
+            if (r2.emitted) r2.notes += std::string("drstencil: note: no geometry option given: the tuner's configuration for this stencil, step, dtype and grid size is used (") + t->options + "); --tuned-defaults 0 keeps the generic defaults\n";
             return r2;
         }
     }

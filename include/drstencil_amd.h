@@ -22,7 +22,7 @@ typedef struct drs_kernel drs_kernel; /* generated, compiled (hipcc, gfx950) and
  * argv excludes the program name.  Returns the process exit code the command would have
  * (0, 1 "No data to reuse", 255 "Illegal input."/"Invalid configuration!"/"Error opening
  * stencil file.").  *source (emitted HIP text, NULL if nothing was emitted) and *messages
- * (stdout text) are malloc'ed; release with drs_free.  No file is written. */
+ * (the command's stdout text, followed by what it prints on stderr: remarks such as "the tuner's configuration ... is used") are malloc'ed; release with drs_free.  No file is written. */
 int drs_generate(int argc, const char *const *argv, char **source, char **messages);
 void drs_free(void *p);
 

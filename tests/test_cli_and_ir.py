@@ -245,6 +245,21 @@ def test_tuned_defaults_table_feeds_generator_and_bench(tmp_path):
     assert "--bx 64 --by 16" in drs.generate(["--3d", "--dtype", "fp32", "--step", "2", near])[1]
 
 
+def test_table_note_goes_to_stderr_not_stdout(tmp_path):
+    """A reference command line (`drstencil --3d --step 2 -o k.cu 3d7pt_star.stc`, main.cpp:10-280) prints nothing on stdout when it succeeds; ours
+    takes the tuner's row for the shipped spec and says so -- on stderr, so that stdout stays the reference's byte for byte (compared with the
+    reference binary itself in oracle/fuzz_vs_reference.py on random shapes, here on the shipped specs that have table rows)."""
+    import subprocess
+    import drstencil_amd as drs
+    for name, flags in (("3d7pt_star", ["--3d"]), ("2d5pt_star", []), ("2d9pt_box", []), ("2d9pt_star", [])):
+        stc = os.path.join(ROOT, "benchmarks", name, name + ".stc")
+        r = subprocess.run([drs.CLI_PATH] + flags + ["--step", "2", "-o", str(tmp_path / (name + ".hip")), stc], capture_output=True, text=True)
+        assert r.returncode == 0 and r.stdout == "", (name, r.stdout[:200])
+        assert "the tuner's configuration" in r.stderr and "--tuned-defaults 0" in r.stderr, (name, r.stderr[:200])
+        r0 = subprocess.run([drs.CLI_PATH] + flags + ["--step", "2", "--tuned-defaults", "0", "-o", str(tmp_path / (name + "_g.hip")), stc], capture_output=True, text=True)
+        assert r0.returncode == 0 and r0.stdout == "" and r0.stderr == "", (name, r0.stderr[:200])
+
+
 def test_tuner_writes_the_defaults_table(tmp_path):
     """tuning.py --write-defaults: the fastest VERIFIED record per (step, temporal, streaming) class becomes the row; naming options are
     stripped; an existing row of the same class and size is replaced, others stay."""
